@@ -1,0 +1,51 @@
+"""Shared pytest plumbing.
+
+* registers the ``gpu`` marker (tests that need an MI355X; run with ``-m gpu``),
+* puts the product package directory and the repo root on ``sys.path``,
+* builds the C oracle on demand (test infrastructure; never used by the product).
+"""
+import json
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+PKG_DIR = ROOT / "napkon-string-matching_amd"
+for p in (str(ROOT), str(PKG_DIR)):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = ROOT / "tests" / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def load_golden(name: str):
+    return json.loads((GOLDEN / name).read_text(encoding="utf-8"))
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden
+
+
+def gpu_available() -> bool:
+    try:
+        import torch
+
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if gpu_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
