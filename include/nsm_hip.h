@@ -1,0 +1,145 @@
+/*
+ * nsm_hip.h -- C ABI of libnsm_hip.so, the MI355X (gfx950) all-pairs scorer that stands in for
+ * the per-pair loop of BIH-CEI/napkon-string-matching.
+ *
+ * Nothing like this exists upstream (the reference is pure Python); each entry point names the
+ * reference code it replaces (paths relative to the reference checkout):
+ *
+ *   nsm_jaccard_raw_grid     score_func `intersection_vs_union` applied to one operand per item
+ *                            (compare/score_functions.py:6-13; the 1xM use in terminology/mesh.py:207-210)
+ *   nsm_indel_raw_grid       score_func `fuzzy_match` = rapidfuzz QRatio/100 on one string per item
+ *                            (compare/score_functions.py:20-27)
+ *   nsm_jaccard_levels_grid  the hot loop of gen_comparable: compare_terms over suffix-nested levels
+ *                            with `intersection_vs_union` (types/comparable_data.py:223-232, :248-265),
+ *                            the category predicate (:464-490) and the `>= score_threshold` filter (:243)
+ *   nsm_indel_levels_grid    the same loop with `fuzzy_match`
+ *   nsm_sort_hits            Comparable.sort_by_score (types/comparable.py:69-70), made deterministic:
+ *                            (score descending, i ascending, j ascending)
+ *
+ * Conventions
+ *   - every pointer marked "device" is HBM memory owned by the caller (the Python host keeps them
+ *     as torch tensors); the library keeps no pointer after a call returns;
+ *   - calls are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - return value: 0 on success, otherwise a hipError_t or one of the NSM_E_* codes below;
+ *     nsm_last_error() gives a thread-local message;
+ *   - data errors that the reference raises as Python exceptions (empty-vs-empty Jaccard ->
+ *     ZeroDivisionError, zero-level item -> IndexError) depend only on per-item properties and are
+ *     detected by the host BEFORE the launch; the kernels define those pairs as "no hit";
+ *   - hits are appended with one atomic counter; *hit_count keeps counting past `capacity`
+ *     (records beyond it are dropped) so the caller can re-run with a larger buffer.
+ */
+#ifndef NSM_HIP_H
+#define NSM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NSM_ABI_VERSION 1
+
+#define NSM_E_BADARG 10001   /* inconsistent sizes / unsupported width */
+#define NSM_E_UNSUPPORTED 10002
+
+/* One above-threshold pair.  16 bytes, the unit of the RCCL all-gather of hits. */
+typedef struct nsm_hit {
+  double score; /* exactly the double the reference computes */
+  int32_t i;    /* caller's left row id  (left_orig[row]) */
+  int32_t j;    /* caller's right row id (right_orig[row]) */
+} nsm_hit;
+
+/* Token-id set table of one side, rows sorted by `cnt` DESCENDING (the encoder does this).
+ *   ids   device int32 [n][width]  unique ids >= 0, unused slots padded (left: -1, right: -2)
+ *   cnt   device int32 [n]         number of ids in the row (RAW) / in the item's largest level
+ *   sig   device uint64[n]         64-bit signature: OR of 1 << ((id * 0x9E3779B1u) >> 26)
+ *   orig  device int32 [n]         caller's row id reported in hits
+ *   -- levels mode only (NULL in RAW mode) --
+ *   nlev  device int32 [n]         number of levels L (>= 1)
+ *   plen  device uint8 [n][max_levels]  level l = the first plen[l] ids of the row (non-decreasing)
+ *   cat   device uint64[n]         category bit mask, NULL when categories are not filtered
+ */
+typedef struct nsm_set_table {
+  const int32_t* ids;
+  const int32_t* cnt;
+  const uint64_t* sig;
+  const int32_t* orig;
+  const int32_t* nlev;
+  const uint8_t* plen;
+  const uint64_t* cat;
+  int32_t n;
+  int32_t width;      /* 16, 32 or 64 */
+  int32_t max_levels; /* row stride of plen */
+} nsm_set_table;
+
+/* Code-unit string table of one side, rows sorted by `len` DESCENDING.
+ *   codes device uint8 [n][stride]  dense alphabet codes (< alphabet), padded with `alphabet`
+ *   len   device int32 [n]
+ *   orig  device int32 [n]          caller's row id (RAW) / unused in levels mode
+ */
+typedef struct nsm_str_table {
+  const uint8_t* codes;
+  const int32_t* len;
+  const int32_t* orig;
+  int32_t n;
+  int32_t stride;   /* 64 (one 64-bit word per pattern); longer strings: NSM_E_UNSUPPORTED */
+  int32_t alphabet; /* number of distinct code units, <= 255 */
+} nsm_str_table;
+
+/* Items whose levels are rows of a nsm_str_table (levels mode of fuzzy_match).
+ *   first  device int32 [n]  row of level 0 in the string table; level l is row first+l
+ *   nlev   device int32 [n]
+ *   orig   device int32 [n]
+ *   cat    device uint64[n] or NULL
+ */
+typedef struct nsm_level_items {
+  const int32_t* first;
+  const int32_t* nlev;
+  const int32_t* orig;
+  const uint64_t* cat;
+  int32_t n;
+} nsm_level_items;
+
+/* Category predicate (types/comparable_data.py:464-476), applied before scoring when both
+ * tables carry `cat`:  match = (cl & cr) != 0  ||  (both_empty_match && cl == 0 && cr == 0). */
+#define NSM_CAT_NONE 0
+#define NSM_CAT_INTERSECT 1            /* scalar x list, list x scalar(bit), scalar x scalar */
+#define NSM_CAT_INTERSECT_OR_BOTH_EMPTY 2 /* list x list */
+
+#define NSM_FLAG_PRUNE 1u /* exact signature / length bound before the full comparison */
+
+int nsm_abi_version(void);
+const char* nsm_last_error(void);
+
+/* RAW Jaccard: every (i, j) with  |A n B| / |A u B|  >= threshold  (IEEE double division and
+ * compare, as Python does).  Pairs with both sets empty never hit (host raises beforehand). */
+int nsm_jaccard_raw_grid(const nsm_set_table* left, const nsm_set_table* right, double threshold,
+                         uint32_t flags, nsm_hit* hits /*device*/, uint64_t capacity,
+                         unsigned long long* hit_count /*device, caller zeroes*/, void* stream);
+
+/* Levels-mode Jaccard: score = sum_{s=1..max(Ll,Lr)} 2^-s * J(level min(s,Ll-1), level min(s,Lr-1))
+ * accumulated in double in that order; optional category predicate. */
+int nsm_jaccard_levels_grid(const nsm_set_table* left, const nsm_set_table* right, double threshold,
+                            int32_t category_mode, uint32_t flags, nsm_hit* hits, uint64_t capacity,
+                            unsigned long long* hit_count, void* stream);
+
+/* RAW Indel ratio: ((1 - (la+lb-2*LCS)/(la+lb)) * 100) / 100, 0 when either string is empty. */
+int nsm_indel_raw_grid(const nsm_str_table* left, const nsm_str_table* right, double threshold,
+                       uint32_t flags, nsm_hit* hits, uint64_t capacity,
+                       unsigned long long* hit_count, void* stream);
+
+/* Levels-mode Indel ratio over per-level strings. */
+int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_table* left_strings,
+                          const nsm_level_items* right, const nsm_str_table* right_strings,
+                          double threshold, int32_t category_mode, uint32_t flags, nsm_hit* hits,
+                          uint64_t capacity, unsigned long long* hit_count, void* stream);
+
+/* In-place canonical ordering of the first min(*hit_count, capacity) hits:
+ * score descending, then i, then j ascending.  `scratch` is a device buffer of the same capacity. */
+int nsm_sort_hits(nsm_hit* hits, nsm_hit* scratch, uint64_t capacity,
+                  const unsigned long long* hit_count, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSM_HIP_H */

@@ -1,0 +1,117 @@
+// Canonical ordering of a hit list: score descending, then i, then j ascending.
+// Stands in for Comparable.sort_by_score (reference: napkon_string_matching/types/comparable.py:69-70,
+// whose quicksort leaves the order of equal scores unspecified; (i, j) is unique per grid, so this
+// order is total and deterministic).
+//
+// The number of hits lives in device memory (the grids append with an atomic counter), so the
+// launch geometry comes from `capacity` and every kernel reads the count itself:
+//   * capacity <= 128 Ki records: rank sort -- each record counts its predecessors in one pass over
+//     LDS-staged tiles and is scattered to scratch[rank]; one launch, no inter-block dependency;
+//   * larger: bitonic network in global memory, "flip" form (all comparators point the same way),
+//     which needs no padding to a power of two; passes beyond the live count exit immediately.
+#include "nsm_common.hpp"
+
+namespace nsm {
+
+__device__ __forceinline__ bool hit_before(const nsm_hit& a, const nsm_hit& b) {
+  if (a.score != b.score) return a.score > b.score;
+  if (a.i != b.i) return a.i < b.i;
+  return a.j < b.j;
+}
+
+__device__ __forceinline__ unsigned long long live_count(const unsigned long long* count,
+                                                         unsigned long long capacity) {
+  const unsigned long long c = *count;
+  return c < capacity ? c : capacity;
+}
+
+__global__ __launch_bounds__(kBlock) void rank_sort_kernel(const nsm_hit* __restrict__ hits,
+                                                           nsm_hit* __restrict__ out,
+                                                           unsigned long long capacity,
+                                                           const unsigned long long* __restrict__ count) {
+  __shared__ nsm_hit tile[kBlock];
+  const unsigned long long n = live_count(count, capacity);
+  const unsigned long long base = static_cast<unsigned long long>(blockIdx.x) * kBlock;
+  if (base >= n) return;  // whole block
+  const unsigned long long idx = base + threadIdx.x;
+  const bool live = idx < n;
+  nsm_hit mine;
+  if (live) mine = hits[idx];
+  unsigned long long rank = 0;
+  for (unsigned long long t0 = 0; t0 < n; t0 += kBlock) {
+    __syncthreads();
+    if (t0 + threadIdx.x < n) tile[threadIdx.x] = hits[t0 + threadIdx.x];
+    __syncthreads();
+    const int m = static_cast<int>(n - t0 < kBlock ? n - t0 : kBlock);
+    if (live) {
+      for (int q = 0; q < m; ++q) rank += hit_before(tile[q], mine) ? 1u : 0u;
+    }
+  }
+  if (live) out[rank] = mine;
+}
+
+__global__ __launch_bounds__(kBlock) void copy_hits_kernel(const nsm_hit* __restrict__ src,
+                                                           nsm_hit* __restrict__ dst,
+                                                           unsigned long long capacity,
+                                                           const unsigned long long* __restrict__ count) {
+  const unsigned long long n = live_count(count, capacity);
+  for (unsigned long long idx = static_cast<unsigned long long>(blockIdx.x) * kBlock + threadIdx.x; idx < n;
+       idx += static_cast<unsigned long long>(gridDim.x) * kBlock)
+    dst[idx] = src[idx];
+}
+
+// One comparator pass of the flip-form bitonic network: k = merge size, j = partner distance
+// (j == 0 marks the first, "flip" step of a merge: partner = idx ^ (k - 1)).
+__global__ __launch_bounds__(kBlock) void bitonic_pass_kernel(nsm_hit* __restrict__ hits,
+                                                              unsigned long long capacity,
+                                                              const unsigned long long* __restrict__ count,
+                                                              unsigned long long k, unsigned long long j) {
+  const unsigned long long n = live_count(count, capacity);
+  if ((k >> 1) >= n) return;  // merges larger than the (virtually padded) list do nothing
+  for (unsigned long long idx = static_cast<unsigned long long>(blockIdx.x) * kBlock + threadIdx.x; idx < n;
+       idx += static_cast<unsigned long long>(gridDim.x) * kBlock) {
+    const unsigned long long partner = j == 0 ? (idx ^ (k - 1)) : (idx ^ j);
+    if (partner > idx && partner < n) {
+      const nsm_hit a = hits[idx];
+      const nsm_hit b = hits[partner];
+      if (hit_before(b, a)) {
+        hits[idx] = b;
+        hits[partner] = a;
+      }
+    }
+  }
+}
+
+constexpr unsigned long long kRankSortMax = 1ull << 17;
+
+}  // namespace nsm
+
+extern "C" int nsm_sort_hits(nsm_hit* hits, nsm_hit* scratch, uint64_t capacity,
+                             const unsigned long long* hit_count, void* stream) {
+  using namespace nsm;
+  if (!hits || !hit_count) {
+    set_error("nsm_sort_hits: null argument");
+    return NSM_E_BADARG;
+  }
+  if (capacity == 0) return 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (capacity <= kRankSortMax) {
+    if (!scratch) {
+      set_error("nsm_sort_hits: scratch buffer required");
+      return NSM_E_BADARG;
+    }
+    const unsigned blocks = static_cast<unsigned>((capacity + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(rank_sort_kernel, dim3(blocks), dim3(kBlock), 0, s, hits, scratch, capacity, hit_count);
+    hipLaunchKernelGGL(copy_hits_kernel, dim3(blocks < 1024 ? blocks : 1024), dim3(kBlock), 0, s, scratch, hits,
+                       capacity, hit_count);
+    return hip_status(hipGetLastError(), "nsm_sort_hits (rank sort)");
+  }
+  unsigned long long blocks64 = (capacity + kBlock - 1) / kBlock;
+  const unsigned blocks = static_cast<unsigned>(blocks64 < 8192 ? blocks64 : 8192);
+  for (unsigned long long k = 2; (k >> 1) < capacity; k <<= 1) {
+    hipLaunchKernelGGL(bitonic_pass_kernel, dim3(blocks), dim3(kBlock), 0, s, hits, capacity, hit_count, k, 0ull);
+    for (unsigned long long j = k >> 2; j > 0; j >>= 1)
+      hipLaunchKernelGGL(bitonic_pass_kernel, dim3(blocks), dim3(kBlock), 0, s, hits, capacity, hit_count, k, j);
+  }
+  return hip_status(hipGetLastError(), "nsm_sort_hits (bitonic)");
+}

@@ -1,0 +1,202 @@
+// Levels-mode Indel-ratio grid: the hot loop of gen_comparable with score_func = fuzzy_match
+// (reference: napkon_string_matching/types/comparable_data.py:223-232 calling compare_terms :248-265
+// and fuzzy_match, compare/score_functions.py:20-27).
+//
+//   score(i, j) = sum_{s=1..max(Ll,Lr)} 2^-s * ratio(left level min(s,Ll-1), right level min(s,Lr-1))
+//
+// Every level of every item is one pre-processed string (the host hoists join_sorted +
+// default_process from per pair to per item) stored as a row of a string table; an item is
+// (first row, number of levels).  Lane = right item, left item wave-uniform.  Per step the wave
+// builds the left level's match-mask table in LDS exactly as the RAW kernel does, each lane loads
+// its own right level row (64 B, re-loaded only when its level index changes) and runs the
+// bit-parallel LCS; the double ratio and the power-of-two weighted sum follow the reference's
+// operation order.
+#include "nsm_common.hpp"
+
+namespace nsm {
+
+struct IndelLevParams {
+  int32_t n_left;
+  int32_t n_right;
+  int32_t rows_per_chunk;
+  int32_t pm_stride;
+  int32_t cat_mode;
+  double threshold;
+  unsigned long long cap;
+};
+
+__device__ __forceinline__ double indel_score_dev(int la, int lb, int lcs) {
+  if (la == 0 || lb == 0) return 0.0;
+  const double maximum = static_cast<double>(la + lb);
+  const double dist = static_cast<double>(la + lb - 2 * lcs);
+  const double norm_sim = 1.0 - dist / maximum;
+  return (norm_sim * 100.0) / 100.0;
+}
+
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, kWave));
+  return v;
+}
+
+__global__ __launch_bounds__(kBlock) void indel_levels_kernel(
+    const int32_t* __restrict__ lfirst, const int32_t* __restrict__ lnlev, const int32_t* __restrict__ lorig,
+    const uint64_t* __restrict__ lcat, const uint8_t* __restrict__ lcodes, const int32_t* __restrict__ llen,
+    const int32_t* __restrict__ rfirst, const int32_t* __restrict__ rnlev, const int32_t* __restrict__ rorig,
+    const uint64_t* __restrict__ rcat, const uint8_t* __restrict__ rcodes, const int32_t* __restrict__ rlen,
+    nsm_hit* __restrict__ hits, unsigned long long* __restrict__ count, const IndelLevParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long s_pm[];  // [wave][pm_stride]
+
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  const int tile = blockIdx.x * kWavesPerBlock + wave;
+  if (tile * kWave >= p.n_right) return;
+  const int j = tile * kWave + lane;
+  const bool valid = j < p.n_right;
+  const int jc = valid ? j : p.n_right - 1;
+
+  const int lr = rnlev[jc];
+  const int rrow0 = rfirst[jc];
+  const int jorig = rorig[jc];
+  const uint64_t catr = (p.cat_mode != NSM_CAT_NONE) ? rcat[jc] : 0ull;
+  const int lr_max = wave_max(valid ? lr : 0);
+
+  unsigned long long* pm = s_pm + wave * p.pm_stride;
+  const int i0 = blockIdx.y * p.rows_per_chunk;
+  const int i1 = min(p.n_left, i0 + p.rows_per_chunk);
+
+  uint32_t text[16];
+  int text_row = -1;
+  int lb = 0;
+
+  for (int i = i0; i < i1; ++i) {
+    bool ok = valid;
+    if (p.cat_mode != NSM_CAT_NONE) ok = ok && category_match(lcat[i], catr, p.cat_mode);
+    if (!__any(ok)) continue;
+    const int ll = lnlev[i];
+    const int lrow0 = lfirst[i];
+    const int steps_w = max(ll, lr_max);
+    const int steps_l = max(ll, lr);
+    double score = 0.0;
+    double factor = 1.0;
+    int pm_row = -1;
+    int la = 0;
+    for (int s = 1; s <= steps_w; ++s) {
+      const bool active = ok && s <= steps_l;
+      // ---- left level (wave-uniform): rebuild the match masks when the level changes
+      const int lrow = lrow0 + max(0, min(s, ll - 1));
+      if (lrow != pm_row) {
+        pm_row = lrow;
+        la = llen[lrow];
+        for (int c = lane; c < p.pm_stride; c += kWave) pm[c] = 0ull;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < la) {
+          const unsigned c = lcodes[static_cast<size_t>(lrow) * 64 + lane];
+          atomicOr(&pm[c], 1ull << lane);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      // ---- right level (per lane): reload the row only when its index changes
+      const int rrow = rrow0 + max(0, min(s, lr - 1));
+      if (rrow != text_row) {
+        text_row = rrow;
+        const uint4* tp = reinterpret_cast<const uint4*>(rcodes + static_cast<size_t>(rrow) * 64);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint4 v = tp[q];
+          text[4 * q + 0] = v.x;
+          text[4 * q + 1] = v.y;
+          text[4 * q + 2] = v.z;
+          text[4 * q + 3] = v.w;
+        }
+        lb = rlen[rrow];
+      }
+      const int nwords = (wave_max(active ? lb : 0) + 3) >> 2;
+      unsigned long long v = ~0ull;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) {
+        if (w < nwords) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const unsigned c = (text[w] >> (8 * b)) & 0xffu;
+            const unsigned long long m = pm[c];
+            const unsigned long long u = v & m;
+            v = (v + u) | (v - u);
+          }
+        }
+      }
+      const int lcs = 64 - __popcll(v);
+      factor *= 0.5;
+      if (active) score += indel_score_dev(la, lb, lcs) * factor;
+    }
+    const bool hit = ok && score >= p.threshold;
+    if (__any(hit)) {
+      if (hit) emit_hit(hits, p.cap, count, score, lorig[i], jorig);
+    }
+  }
+}
+
+}  // namespace nsm
+
+extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_table* left_strings,
+                                     const nsm_level_items* right, const nsm_str_table* right_strings,
+                                     double threshold, int32_t category_mode, uint32_t flags, nsm_hit* hits,
+                                     uint64_t capacity, unsigned long long* hit_count, void* stream) {
+  using namespace nsm;
+  (void)flags;
+  if (!left || !right || !left_strings || !right_strings || !hit_count || (!hits && capacity)) {
+    set_error("nsm_indel_levels_grid: null argument");
+    return NSM_E_BADARG;
+  }
+  if (left_strings->stride != 64 || right_strings->stride != 64) {
+    set_error("nsm_indel_levels_grid: stride %d/%d unsupported (level strings longer than 64 code units)",
+              left_strings->stride, right_strings->stride);
+    return NSM_E_UNSUPPORTED;
+  }
+  if (left_strings->alphabet != right_strings->alphabet || left_strings->alphabet < 1 ||
+      left_strings->alphabet > 255) {
+    set_error("nsm_indel_levels_grid: alphabets differ or exceed 255");
+    return NSM_E_BADARG;
+  }
+  if (category_mode != NSM_CAT_NONE && category_mode != NSM_CAT_INTERSECT &&
+      category_mode != NSM_CAT_INTERSECT_OR_BOTH_EMPTY) {
+    set_error("nsm_indel_levels_grid: unknown category mode %d", category_mode);
+    return NSM_E_BADARG;
+  }
+  if (left->n < 0 || right->n < 0) {
+    set_error("nsm_indel_levels_grid: negative row count");
+    return NSM_E_BADARG;
+  }
+  if (left->n == 0 || right->n == 0) return 0;
+  if (!left->first || !left->nlev || !left->orig || !right->first || !right->nlev || !right->orig ||
+      !left_strings->codes || !left_strings->len || !right_strings->codes || !right_strings->len ||
+      (category_mode != NSM_CAT_NONE && (!left->cat || !right->cat))) {
+    set_error("nsm_indel_levels_grid: table has a null column");
+    return NSM_E_BADARG;
+  }
+  IndelLevParams p;
+  p.n_left = left->n; p.n_right = right->n; p.cap = capacity;
+  p.pm_stride = ((left_strings->alphabet + 1) + 63) / 64 * 64;
+  p.cat_mode = category_mode;
+  p.threshold = threshold;
+  const int n_tiles = (right->n + kWave - 1) / kWave;
+  const long long want_waves = 16ll * 256 * 32;
+  long long chunks = (want_waves + n_tiles - 1) / n_tiles;
+  long long rows = (left->n + chunks - 1) / chunks;
+  if (rows < 32) rows = 32;
+  if (rows > 4096) rows = 4096;
+  p.rows_per_chunk = static_cast<int>(rows);
+  dim3 grid((n_tiles + kWavesPerBlock - 1) / kWavesPerBlock, (left->n + p.rows_per_chunk - 1) / p.rows_per_chunk);
+  if (grid.y > 65535) {
+    p.rows_per_chunk = (left->n + 65534) / 65535;
+    grid.y = (left->n + p.rows_per_chunk - 1) / p.rows_per_chunk;
+  }
+  const size_t lds = static_cast<size_t>(kWavesPerBlock) * p.pm_stride * 8;
+  hipLaunchKernelGGL(indel_levels_kernel, grid, dim3(kBlock), lds, static_cast<hipStream_t>(stream), left->first,
+                     left->nlev, left->orig, left->cat, left_strings->codes, left_strings->len, right->first,
+                     right->nlev, right->orig, right->cat, right_strings->codes, right_strings->len, hits, hit_count,
+                     p);
+  return hip_status(hipGetLastError(), "indel_levels_kernel launch");
+}

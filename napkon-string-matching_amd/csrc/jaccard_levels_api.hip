@@ -1,0 +1,57 @@
+// C ABI entry point of the levels-mode Jaccard grid (include/nsm_hip.h).
+#include "nsm_common.hpp"
+
+namespace nsm {
+template <int W>
+int launch_levels(const nsm_set_table* l, const nsm_set_table* r, double threshold, int32_t category_mode,
+                  uint32_t flags, nsm_hit* hits, uint64_t capacity, unsigned long long* hit_count,
+                  hipStream_t stream);
+#define NSM_DECL(W)                                                                                      \
+  extern template int launch_levels<W>(const nsm_set_table*, const nsm_set_table*, double, int32_t, uint32_t, \
+                                       nsm_hit*, uint64_t, unsigned long long*, hipStream_t);
+NSM_DECL(16)
+NSM_DECL(32)
+NSM_DECL(64)
+#undef NSM_DECL
+}  // namespace nsm
+
+extern "C" int nsm_jaccard_levels_grid(const nsm_set_table* left, const nsm_set_table* right, double threshold,
+                                       int32_t category_mode, uint32_t flags, nsm_hit* hits, uint64_t capacity,
+                                       unsigned long long* hit_count, void* stream) {
+  using namespace nsm;
+  if (!left || !right || !hit_count || (!hits && capacity)) {
+    set_error("nsm_jaccard_levels_grid: null argument");
+    return NSM_E_BADARG;
+  }
+  if (left->width != right->width) {
+    set_error("nsm_jaccard_levels_grid: left width %d != right width %d", left->width, right->width);
+    return NSM_E_BADARG;
+  }
+  if (left->n < 0 || right->n < 0 || left->max_levels < 1 || right->max_levels < 1) {
+    set_error("nsm_jaccard_levels_grid: bad row count or level stride");
+    return NSM_E_BADARG;
+  }
+  if (category_mode != NSM_CAT_NONE && category_mode != NSM_CAT_INTERSECT &&
+      category_mode != NSM_CAT_INTERSECT_OR_BOTH_EMPTY) {
+    set_error("nsm_jaccard_levels_grid: unknown category mode %d", category_mode);
+    return NSM_E_BADARG;
+  }
+  if (left->n == 0 || right->n == 0) return 0;
+  const nsm_set_table* t[2] = {left, right};
+  for (int k = 0; k < 2; ++k) {
+    if (!t[k]->ids || !t[k]->cnt || !t[k]->sig || !t[k]->orig || !t[k]->nlev || !t[k]->plen ||
+        (category_mode != NSM_CAT_NONE && !t[k]->cat)) {
+      set_error("nsm_jaccard_levels_grid: %s table has a null column", k ? "right" : "left");
+      return NSM_E_BADARG;
+    }
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (left->width) {
+    case 16: return launch_levels<16>(left, right, threshold, category_mode, flags, hits, capacity, hit_count, s);
+    case 32: return launch_levels<32>(left, right, threshold, category_mode, flags, hits, capacity, hit_count, s);
+    case 64: return launch_levels<64>(left, right, threshold, category_mode, flags, hits, capacity, hit_count, s);
+    default:
+      set_error("nsm_jaccard_levels_grid: width %d not in {16, 32, 64}", left->width);
+      return NSM_E_UNSUPPORTED;
+  }
+}

@@ -1,0 +1,113 @@
+"""ctypes binding of ``libnsm_hip.so`` (C ABI: include/nsm_hip.h).  Fails loudly."""
+import ctypes
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("NSM_HIP_LIBRARY", _HERE.parent / "csrc" / "libnsm_hip.so"))
+
+ABI_VERSION = 1
+FLAG_PRUNE = 1
+CAT_NONE, CAT_INTERSECT, CAT_INTERSECT_OR_BOTH_EMPTY = 0, 1, 2
+
+c_i32p = ctypes.c_void_p  # device pointers travel as integers
+c_u64 = ctypes.c_uint64
+
+
+class NsmHit(ctypes.Structure):
+    _fields_ = [("score", ctypes.c_double), ("i", ctypes.c_int32), ("j", ctypes.c_int32)]
+
+
+class NsmSetTable(ctypes.Structure):
+    _fields_ = [
+        ("ids", ctypes.c_void_p),
+        ("cnt", ctypes.c_void_p),
+        ("sig", ctypes.c_void_p),
+        ("orig", ctypes.c_void_p),
+        ("nlev", ctypes.c_void_p),
+        ("plen", ctypes.c_void_p),
+        ("cat", ctypes.c_void_p),
+        ("n", ctypes.c_int32),
+        ("width", ctypes.c_int32),
+        ("max_levels", ctypes.c_int32),
+    ]
+
+
+class NsmStrTable(ctypes.Structure):
+    _fields_ = [
+        ("codes", ctypes.c_void_p),
+        ("len", ctypes.c_void_p),
+        ("orig", ctypes.c_void_p),
+        ("n", ctypes.c_int32),
+        ("stride", ctypes.c_int32),
+        ("alphabet", ctypes.c_int32),
+    ]
+
+
+class NsmLevelItems(ctypes.Structure):
+    _fields_ = [
+        ("first", ctypes.c_void_p),
+        ("nlev", ctypes.c_void_p),
+        ("orig", ctypes.c_void_p),
+        ("cat", ctypes.c_void_p),
+        ("n", ctypes.c_int32),
+    ]
+
+
+EXPORTS = (
+    "nsm_abi_version",
+    "nsm_last_error",
+    "nsm_jaccard_raw_grid",
+    "nsm_jaccard_levels_grid",
+    "nsm_indel_raw_grid",
+    "nsm_indel_levels_grid",
+    "nsm_sort_hits",
+)
+
+_lib = None
+
+
+class NsmLibraryError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load the in-tree HIP library once.  No fallback: a missing library is an error."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise NsmLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the match loop."
+        )
+    lib = ctypes.CDLL(str(LIB_PATH))
+    lib.nsm_abi_version.restype = ctypes.c_int
+    lib.nsm_last_error.restype = ctypes.c_char_p
+    if lib.nsm_abi_version() != ABI_VERSION:
+        raise NsmLibraryError(f"{LIB_PATH}: ABI {lib.nsm_abi_version()} != expected {ABI_VERSION}")
+    P = ctypes.POINTER
+    grid_tail = [ctypes.c_void_p, c_u64, ctypes.c_void_p, ctypes.c_void_p]  # hits, capacity, hit_count, stream
+    lib.nsm_jaccard_raw_grid.argtypes = [P(NsmSetTable), P(NsmSetTable), ctypes.c_double, ctypes.c_uint32] + grid_tail
+    lib.nsm_jaccard_levels_grid.argtypes = [
+        P(NsmSetTable), P(NsmSetTable), ctypes.c_double, ctypes.c_int32, ctypes.c_uint32] + grid_tail
+    lib.nsm_indel_raw_grid.argtypes = [P(NsmStrTable), P(NsmStrTable), ctypes.c_double, ctypes.c_uint32] + grid_tail
+    lib.nsm_indel_levels_grid.argtypes = [
+        P(NsmLevelItems), P(NsmStrTable), P(NsmLevelItems), P(NsmStrTable),
+        ctypes.c_double, ctypes.c_int32, ctypes.c_uint32] + grid_tail
+    lib.nsm_sort_hits.argtypes = [ctypes.c_void_p, ctypes.c_void_p, c_u64, ctypes.c_void_p, ctypes.c_void_p]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name not in ("nsm_last_error",):
+            fn.restype = ctypes.c_int
+    lib.nsm_last_error.restype = ctypes.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load().nsm_last_error().decode("utf-8", "replace")
+        if status == 10002:
+            raise NotImplementedError(f"{what}: {msg}")
+        raise NsmLibraryError(f"{what} failed with status {status}: {msg}")

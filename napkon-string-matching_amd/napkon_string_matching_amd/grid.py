@@ -1,0 +1,172 @@
+"""Launch wrappers: one N x M pair grid -> the list of above-threshold hits.
+
+This is the device half of the reference's per-pair loop
+(``gen_comparable``: types/comparable_data.py:223-232,243 and ``compare``: :123-126).  The
+per-item error surfaces of the reference (``ZeroDivisionError`` for empty-vs-empty Jaccard,
+score_functions.py:13; ``IndexError`` for a zero-level item, comparable_data.py:262) are raised
+here, before the launch, from per-item properties; the kernels never see such a pair as a hit.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .tables import LevelItems, SetTable, StrTable
+
+HIT_BYTES = 16
+DEFAULT_CAPACITY = 1 << 20
+
+
+@dataclass
+class Hits:
+    """Above-threshold pairs in canonical order (score descending, then i, then j)."""
+
+    score: np.ndarray  # float64
+    i: np.ndarray  # int32, caller's left item index
+    j: np.ndarray  # int32, caller's right item index
+
+    def __len__(self) -> int:
+        return int(self.score.shape[0])
+
+    def as_tuples(self):
+        return list(zip(self.score.tolist(), self.i.tolist(), self.j.tolist()))
+
+
+def _require_gpu(device) -> torch.device:
+    dev = torch.device(device)
+    if dev.type != "cuda" or not torch.cuda.is_available():
+        raise _lib.NsmLibraryError(
+            "the match loop only runs on an MI355X (HIP device); there is no CPU fallback"
+        )
+    return dev
+
+
+class HitBuffer:
+    """Caller-owned hit storage: ``capacity`` 16-byte records + the device counter."""
+
+    def __init__(self, capacity: int, device) -> None:
+        self.capacity = int(capacity)
+        self.records = torch.empty((max(1, self.capacity), 2), dtype=torch.float64, device=device)
+        self.scratch: Optional[torch.Tensor] = None
+        self.count = torch.zeros(1, dtype=torch.int64, device=device)
+
+    def reset(self) -> None:
+        self.count.zero_()
+
+    def views(self, n: int):
+        score = self.records[:n, 0]
+        ij = self.records.view(torch.int32).view(-1, 4)[:n, 2:4]
+        return score, ij[:, 0], ij[:, 1]
+
+
+def sort_hits_device(buf: HitBuffer, n: int) -> Hits:
+    """Canonical order on the device, then one D2H copy of the n records."""
+    if n == 0:
+        return Hits(np.zeros(0, np.float64), np.zeros(0, np.int32), np.zeros(0, np.int32))
+    lib = _lib.load()
+    if buf.scratch is None or buf.scratch.shape[0] < buf.records.shape[0]:
+        buf.scratch = torch.empty_like(buf.records)
+    stream = torch.cuda.current_stream(buf.records.device).cuda_stream
+    _lib.check(
+        lib.nsm_sort_hits(buf.records.data_ptr(), buf.scratch.data_ptr(), buf.capacity, buf.count.data_ptr(), stream),
+        "nsm_sort_hits",
+    )
+    host = buf.records[:n].cpu().numpy()
+    ij = host.view(np.int32).reshape(n, 4)
+    return Hits(host[:, 0].copy(), ij[:, 2].copy(), ij[:, 3].copy())
+
+
+def run_grid(launch: Callable[[HitBuffer, int], int], device, capacity: Optional[int], what: str) -> Hits:
+    """Run ``launch`` with a hit buffer, growing it once if the counter overflowed."""
+    dev = _require_gpu(device)
+    buf = HitBuffer(capacity or DEFAULT_CAPACITY, dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    for _attempt in range(2):
+        buf.reset()
+        _lib.check(launch(buf, stream), what)
+        n = int(buf.count.item())  # synchronises the stream
+        if n <= buf.capacity:
+            return sort_hits_device(buf, n)
+        buf = HitBuffer(n, dev)
+    raise _lib.NsmLibraryError(f"{what}: hit count changed between two identical launches")
+
+
+# ------------------------------------------------------------------------------- RAW grids
+def jaccard_raw_grid(
+    left: SetTable, right: SetTable, threshold: float, prune: bool = True, capacity: Optional[int] = None
+) -> Hits:
+    """``intersection_vs_union`` on one set per item, all N x M pairs, hits ``>= threshold``."""
+    if left.side != "left" or right.side != "right":
+        raise ValueError("tables must be encoded with side='left' and side='right' (distinct padding)")
+    if left.has_empty and right.has_empty:
+        # score_functions.py:13 -- len(set() | set()) == 0
+        raise ZeroDivisionError("division by zero")
+    lib = _lib.load()
+    ls, rs = left.struct(), right.struct()
+    flags = _lib.FLAG_PRUNE if prune else 0
+
+    def launch(buf: HitBuffer, stream: int) -> int:
+        return lib.nsm_jaccard_raw_grid(
+            ls, rs, float(threshold), flags, buf.records.data_ptr(), buf.capacity, buf.count.data_ptr(), stream
+        )
+
+    return run_grid(launch, left.ids.device, capacity, "nsm_jaccard_raw_grid")
+
+
+def indel_raw_grid(
+    left: StrTable, right: StrTable, threshold: float, prune: bool = True, capacity: Optional[int] = None
+) -> Hits:
+    """``fuzzy_match`` (QRatio/100 = Indel ratio after default_process) on one string per item."""
+    lib = _lib.load()
+    ls, rs = left.struct(), right.struct()
+    flags = _lib.FLAG_PRUNE if prune else 0
+
+    def launch(buf: HitBuffer, stream: int) -> int:
+        return lib.nsm_indel_raw_grid(
+            ls, rs, float(threshold), flags, buf.records.data_ptr(), buf.capacity, buf.count.data_ptr(), stream
+        )
+
+    return run_grid(launch, left.codes.device, capacity, "nsm_indel_raw_grid")
+
+
+# ------------------------------------------------------------------------------- levels grids
+def jaccard_levels_grid(
+    left: SetTable, right: SetTable, threshold: float, category_mode: int = _lib.CAT_NONE, prune: bool = True,
+    capacity: Optional[int] = None,
+) -> Hits:
+    """``compare_terms`` with ``intersection_vs_union`` over suffix-nested levels."""
+    if left.nlev is None or right.nlev is None:
+        raise ValueError("levels grid needs tables built with SetTable.from_levels")
+    lib = _lib.load()
+    ls, rs = left.struct(), right.struct()
+    flags = _lib.FLAG_PRUNE if prune else 0
+
+    def launch(buf: HitBuffer, stream: int) -> int:
+        return lib.nsm_jaccard_levels_grid(
+            ls, rs, float(threshold), int(category_mode), flags, buf.records.data_ptr(), buf.capacity,
+            buf.count.data_ptr(), stream,
+        )
+
+    return run_grid(launch, left.ids.device, capacity, "nsm_jaccard_levels_grid")
+
+
+def indel_levels_grid(
+    left: LevelItems, left_strings: StrTable, right: LevelItems, right_strings: StrTable, threshold: float,
+    category_mode: int = _lib.CAT_NONE, prune: bool = True, capacity: Optional[int] = None,
+) -> Hits:
+    """``compare_terms`` with ``fuzzy_match`` over per-level strings."""
+    lib = _lib.load()
+    li, ls, ri, rs = left.struct(), left_strings.struct(), right.struct(), right_strings.struct()
+    flags = _lib.FLAG_PRUNE if prune else 0
+
+    def launch(buf: HitBuffer, stream: int) -> int:
+        return lib.nsm_indel_levels_grid(
+            li, ls, ri, rs, float(threshold), int(category_mode), flags, buf.records.data_ptr(), buf.capacity,
+            buf.count.data_ptr(), stream,
+        )
+
+    return run_grid(launch, left.first.device, capacity, "nsm_indel_levels_grid")

@@ -1,0 +1,142 @@
+"""Synthetic corpora of the BASELINE.json configurations.
+
+There is no dataset to download (the reference's real inputs are private NAPKON files), so
+every benchmark and parity test runs on these generators.  All are seeded and vectorised.
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import numpy as np
+
+STRING_ALPHABET = "abcdefghijklmnopqrstuvwxyz0123456789 "  # fixed point of default_process
+SPACE_CODE = len(STRING_ALPHABET) - 1
+
+
+# ------------------------------------------------------------------ C2 / C4: token-id sets
+def token_sets(n: int, seed: int, mean: float = 8.0, width: int = 16, id_range: int = 1 << 17) -> np.ndarray:
+    """int32 [n][width], each row a sorted set of clip(Poisson(mean), 1, width) distinct ids
+    drawn from U[0, id_range), padded with -1."""
+    rng = np.random.default_rng(seed)
+    size = np.clip(rng.poisson(mean, n), 1, width).astype(np.int32)
+    ids = rng.integers(0, id_range, size=(n, width), dtype=np.int64)
+    while True:  # re-draw the (rare) rows that drew one id twice
+        srt = np.sort(ids, axis=1)
+        bad = (srt[:, 1:] == srt[:, :-1]).any(axis=1)
+        if not bad.any():
+            break
+        ids[bad] = rng.integers(0, id_range, size=(int(bad.sum()), width), dtype=np.int64)
+    big = np.iinfo(np.int64).max
+    ids[np.arange(width)[None, :] >= size[:, None]] = big
+    ids.sort(axis=1)
+    ids[ids == big] = -1
+    return ids.astype(np.int32)
+
+
+def plant_near_duplicate_sets(
+    left: np.ndarray, right: np.ndarray, seed: int, fraction: float = 0.01, id_range: int = 1 << 17
+) -> np.ndarray:
+    """Overwrite ``fraction`` of the right rows with copies of random left rows in which at most
+    one id was replaced (guarantees above-threshold pairs)."""
+    rng = np.random.default_rng(seed)
+    right = right.copy()
+    n_plant = max(1, int(round(fraction * right.shape[0])))
+    targets = rng.choice(right.shape[0], size=n_plant, replace=False)
+    sources = rng.integers(0, left.shape[0], size=n_plant)
+    for t, s in zip(targets, sources):
+        row = left[s].copy()
+        k = int((row >= 0).sum())
+        if rng.random() < 0.5 and k > 0:
+            new = int(rng.integers(0, id_range))
+            if new not in row[:k]:
+                row[int(rng.integers(0, k))] = new
+                vals = np.sort(row[:k])
+                row[:k] = vals
+        right[t] = row
+    return right
+
+
+def c2_corpus(n: int = 50_000, m: int = 50_000, seed_left: int = 1234, seed_right: int = 5678):
+    left = token_sets(n, seed_left)
+    right = plant_near_duplicate_sets(left, token_sets(m, seed_right), seed_right + 1)
+    return left, right
+
+
+# ------------------------------------------------------------------ C3: strings
+def strings(n: int, seed: int, lo: int = 16, hi: int = 64) -> Tuple[np.ndarray, np.ndarray]:
+    """uint8 codes [n][64] over STRING_ALPHABET with length ~ U[lo, hi]; no leading / trailing
+    blank (so every string is a fixed point of default_process)."""
+    rng = np.random.default_rng(seed)
+    length = rng.integers(lo, hi + 1, size=n).astype(np.int32)
+    codes = rng.integers(0, len(STRING_ALPHABET), size=(n, 64), dtype=np.int64).astype(np.uint8)
+    first = codes[:, 0]
+    first[first == SPACE_CODE] = 0
+    last = codes[np.arange(n), length - 1]
+    last[last == SPACE_CODE] = 1
+    codes[np.arange(n), length - 1] = last
+    codes[np.arange(64)[None, :] >= length[:, None]] = 0
+    return codes, length
+
+
+def plant_near_duplicate_strings(
+    left: Tuple[np.ndarray, np.ndarray], right: Tuple[np.ndarray, np.ndarray], seed: int, fraction: float = 0.01
+):
+    """Overwrite ``fraction`` of the right strings with copies of random left strings carrying up
+    to 10 % random substitutions."""
+    rng = np.random.default_rng(seed)
+    lc, ll = left
+    rc, rl = right[0].copy(), right[1].copy()
+    n_plant = max(1, int(round(fraction * rc.shape[0])))
+    targets = rng.choice(rc.shape[0], size=n_plant, replace=False)
+    sources = rng.integers(0, lc.shape[0], size=n_plant)
+    for t, s in zip(targets, sources):
+        row, length = lc[s].copy(), int(ll[s])
+        for _ in range(int(rng.integers(0, length // 10 + 1))):
+            pos = int(rng.integers(1, max(2, length - 1)))
+            row[pos] = rng.integers(0, SPACE_CODE)  # never a blank: keeps the fixed point
+        rc[t], rl[t] = row, length
+    return rc, rl
+
+
+def c3_corpus(n: int = 200_000, m: int = 200_000, seed_left: int = 1234, seed_right: int = 5678):
+    left = strings(n, seed_left)
+    right = plant_near_duplicate_strings(left, strings(m, seed_right), seed_right + 1)
+    return left, right
+
+
+def decode_strings(codes: np.ndarray, length: np.ndarray) -> List[str]:
+    return ["".join(STRING_ALPHABET[c] for c in row[:k]) for row, k in zip(codes, length)]
+
+
+def decode_sets(ids: np.ndarray) -> List[List[str]]:
+    """Token lists as the reference's plugin would see them (``str`` tokens)."""
+    return [[f"t{v}" for v in row if v >= 0] for row in ids]
+
+
+# ------------------------------------------------------------------ C1 / C5: cohorts
+def cohort_records(
+    name: str, n: int, seed: int, vocab: int = 500, max_entries: int = 8, tokens_per_entry: int = 1,
+    n_categories: int = 8, min_entries: int = 1,
+) -> list:
+    """hap / pop / suep shaped items: ``Tokens`` is a list of entries, each a blank-joined group
+    of ``t<id>`` words, so that gen_comp_value yields one suffix-nested level per entry."""
+    rng = np.random.default_rng(seed)
+    rows = []
+    for k in range(n):
+        entries = [
+            " ".join(f"t{int(v)}" for v in rng.integers(0, vocab, size=tokens_per_entry))
+            for _ in range(int(rng.integers(min_entries, max_entries + 1)))
+        ]
+        cats = sorted(f"cat{int(c)}" for c in rng.choice(n_categories, size=int(rng.integers(1, 3)), replace=False))
+        rows.append(
+            {
+                "Identifier": f"{name}#sheet{k % 7}#{k}",
+                "Variable": f"{name}_var_{k}",
+                "Sheet": f"sheet{k % 7}",
+                "Category": cats,
+                "Term": [f"header{k % 5}", f"question {k}"],
+                "Tokens": entries,
+                "Parameter": f"param{k}",
+            }
+        )
+    return rows

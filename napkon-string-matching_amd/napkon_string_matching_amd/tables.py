@@ -1,0 +1,385 @@
+"""Host encoders: per-item operands -> HBM tables the HIP kernels read (include/nsm_hip.h).
+
+Everything here is per-ITEM work (O(N + M)); the per-PAIR work is on the GPU.  The reference does
+the equivalent per-item preparation in ``ComparableData.gen_comp_value`` / ``tokenize``
+(types/comparable_data.py:283-299) and -- wastefully, once per pair -- in ``join_sorted`` and
+``set(...)`` (compare/score_functions.py:10-11,16-17,24-25).
+
+Layouts (one row per item, rows sorted by size descending so that a wavefront's 64 rows have the
+same size class; ``orig`` maps a row back to the caller's item index):
+
+* ``SetTable``  int32 ids [n][W], W in {16, 32, 64}; unused slots hold -1 (left) / -2 (right) so
+  that padding never compares equal; ``cnt``; a 64-bit signature per row for the exact prune.
+  In levels mode the ids are stored in "suffix-nested" order: level l of the item is the first
+  ``plen[l]`` ids, so ONE equality matrix per pair serves every level.
+* ``StrTable``  uint8 codes [n][64] over a dense per-corpus alphabet (<= 255 symbols), padded with
+  the code ``alphabet``; ``len``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Hashable, Iterable, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+
+WIDTHS = (16, 32, 64)
+MAX_LEVELS = 64
+LEFT_PAD, RIGHT_PAD = -1, -2
+_GOLDEN = np.uint32(0x9E3779B1)
+
+
+def pick_width(*max_counts: int) -> int:
+    need = max([1, *max_counts])
+    for w in WIDTHS:
+        if need <= w:
+            return w
+    raise NotImplementedError(
+        f"an item has {need} distinct tokens; the HIP kernels hold one row in at most {WIDTHS[-1]} registers"
+    )
+
+
+def signatures(ids: np.ndarray, cnt: np.ndarray) -> np.ndarray:
+    """64-bit row signature: bit ((id * 0x9E3779B1) >> 26) for every id of the row."""
+    n, w = ids.shape
+    valid = np.arange(w, dtype=np.int32)[None, :] < cnt[:, None]
+    h = ((ids.astype(np.uint32) * _GOLDEN) >> np.uint32(26)).astype(np.uint64)
+    bits = np.where(valid, np.uint64(1) << h, np.uint64(0))
+    return np.bitwise_or.reduce(bits, axis=1) if n else np.zeros(0, np.uint64)
+
+
+def _dev(array: np.ndarray, device) -> torch.Tensor:
+    return torch.from_numpy(np.ascontiguousarray(array)).to(device)
+
+
+class Vocabulary:
+    """Equality-preserving token -> dense int32 id map shared by both sides of a grid."""
+
+    def __init__(self) -> None:
+        self._ids: Dict[Hashable, int] = {}
+
+    def id(self, token: Hashable) -> int:
+        got = self._ids.get(token)
+        if got is None:
+            got = len(self._ids)
+            self._ids[token] = got
+        return got
+
+    def __len__(self) -> int:
+        return len(self._ids)
+
+
+@dataclass
+class SetTable:
+    ids: torch.Tensor
+    cnt: torch.Tensor
+    sig: torch.Tensor
+    orig: torch.Tensor
+    side: str
+    width: int
+    n: int
+    has_empty: bool
+    nlev: Optional[torch.Tensor] = None
+    plen: Optional[torch.Tensor] = None
+    cat: Optional[torch.Tensor] = None
+    max_levels: int = 0
+
+    # ------------------------------------------------------------------ builders
+    @classmethod
+    def from_padded(
+        cls,
+        ids: np.ndarray,
+        side: str,
+        device,
+        width: Optional[int] = None,
+        orig: Optional[np.ndarray] = None,
+        validate: bool = True,
+    ) -> "SetTable":
+        """RAW table from an int array [n][w]; negative entries are padding, the rest must be
+        unique per row (``validate`` checks)."""
+        ids = np.asarray(ids)
+        if ids.ndim != 2:
+            raise ValueError("ids must be [n][w]")
+        n, w_in = ids.shape
+        valid = ids >= 0
+        cnt = valid.sum(axis=1).astype(np.int32)
+        width = width or pick_width(int(cnt.max()) if n else 1)
+        if n and int(cnt.max()) > width:
+            raise ValueError(f"row with {int(cnt.max())} ids does not fit width {width}")
+        order = np.argsort(~valid, axis=1, kind="stable")  # valid ids first, input order kept
+        packed = np.take_along_axis(ids, order, axis=1)[:, : min(w_in, width)].astype(np.int32)
+        if packed.shape[1] < width:
+            packed = np.pad(packed, ((0, 0), (0, width - packed.shape[1])), constant_values=-1)
+        if validate and n:
+            srt = np.sort(np.where(packed >= 0, packed, -np.arange(1, width + 1, dtype=np.int64)[None, :]), axis=1)
+            if (srt[:, 1:] == srt[:, :-1]).any():
+                raise ValueError("duplicate id inside a row: sets must be de-duplicated before encoding")
+        return cls._finish(packed, cnt, side, device, width, orig)
+
+    @classmethod
+    def from_rows(
+        cls, rows: Sequence[Iterable[Hashable]], side: str, device, vocab: Vocabulary, width: Optional[int] = None
+    ) -> "SetTable":
+        """RAW table from Python collections of hashable tokens (duplicates collapse like ``set``)."""
+        uniq: List[List[int]] = []
+        for row in rows:
+            seen: Dict[int, None] = {}
+            for tok in row:
+                seen.setdefault(vocab.id(tok), None)
+            uniq.append(list(seen))
+        width = width or pick_width(max((len(u) for u in uniq), default=1))
+        ids = np.full((len(uniq), width), -1, dtype=np.int32)
+        for k, u in enumerate(uniq):
+            if len(u) > width:
+                raise ValueError(f"row {k} has {len(u)} ids > width {width}")
+            ids[k, : len(u)] = u
+        return cls.from_padded(ids, side, device, width=width, validate=False)
+
+    @classmethod
+    def from_levels(
+        cls,
+        items: Sequence[Sequence[Iterable[Hashable]]],
+        side: str,
+        device,
+        vocab: Vocabulary,
+        width: Optional[int] = None,
+        categories: Optional[np.ndarray] = None,
+    ) -> "SetTable":
+        """Levels table.  ``items[k]`` is the level list of item k (``gen_comp_value`` output,
+        types/comparable_data.py:283-285): level l must contain level l-1 (suffix nesting)."""
+        n = len(items)
+        orders: List[List[int]] = []
+        plens: List[List[int]] = []
+        for k, levels in enumerate(items):
+            if len(levels) > MAX_LEVELS:
+                raise NotImplementedError(f"item {k} has {len(levels)} levels > {MAX_LEVELS}")
+            seen: Dict[int, None] = {}
+            pl: List[int] = []
+            for level in levels:
+                before = len(seen)
+                distinct = 0
+                ids_here = {vocab.id(tok) for tok in level}
+                for tok in level:
+                    seen.setdefault(vocab.id(tok), None)
+                distinct = len(ids_here)
+                if distinct != len(seen):
+                    # some earlier id is missing from this level: not suffix-nested
+                    raise NotImplementedError(
+                        f"item {k}: level {len(pl)} does not contain level {len(pl) - 1}; only "
+                        "suffix-nested levels (what gen_comp_value produces) are supported on the GPU"
+                    )
+                del before
+                pl.append(len(seen))
+            orders.append(list(seen))
+            plens.append(pl)
+        width = width or pick_width(max((len(o) for o in orders), default=1))
+        max_levels = max(4, -(-max((len(p) for p in plens), default=1) // 4) * 4)
+        ids = np.full((n, width), -1, dtype=np.int32)
+        plen = np.zeros((n, max_levels), dtype=np.uint8)
+        nlev = np.zeros(n, dtype=np.int32)
+        for k, (o, pl) in enumerate(zip(orders, plens)):
+            if len(o) > width:
+                raise ValueError(f"item {k} has {len(o)} ids > width {width}")
+            ids[k, : len(o)] = o
+            nlev[k] = len(pl)
+            plen[k, : len(pl)] = pl
+            if pl:
+                plen[k, len(pl):] = pl[-1]
+        cnt = (ids >= 0).sum(axis=1).astype(np.int32)
+        return cls._finish(ids, cnt, side, device, width, None, nlev=nlev, plen=plen, cat=categories, max_levels=max_levels)
+
+    @classmethod
+    def _finish(cls, ids, cnt, side, device, width, orig, nlev=None, plen=None, cat=None, max_levels=0):
+        if side not in ("left", "right"):
+            raise ValueError("side must be 'left' or 'right'")
+        n = ids.shape[0]
+        ids = ids.copy()
+        pad = LEFT_PAD if side == "left" else RIGHT_PAD
+        ids[np.arange(width, dtype=np.int32)[None, :] >= cnt[:, None]] = pad
+        perm = np.argsort(-cnt, kind="stable")  # size descending, ties by input order
+        base = np.arange(n, dtype=np.int32) if orig is None else np.asarray(orig, dtype=np.int32)
+        ids, cnt_s = ids[perm], cnt[perm]
+        return cls(
+            ids=_dev(ids, device),
+            cnt=_dev(cnt_s, device),
+            sig=_dev(signatures(ids, cnt_s), device),
+            orig=_dev(base[perm], device),
+            side=side,
+            width=width,
+            n=n,
+            has_empty=bool(n and cnt.min() == 0),
+            nlev=None if nlev is None else _dev(nlev[perm], device),
+            plen=None if plen is None else _dev(plen[perm], device),
+            cat=None if cat is None else _dev(np.asarray(cat, dtype=np.uint64)[perm], device),
+            max_levels=max_levels,
+        )
+
+    # ------------------------------------------------------------------ C view
+    def struct(self) -> _lib.NsmSetTable:
+        def ptr(t):
+            return None if t is None else t.data_ptr()
+
+        return _lib.NsmSetTable(
+            ptr(self.ids), ptr(self.cnt), ptr(self.sig), ptr(self.orig), ptr(self.nlev), ptr(self.plen),
+            ptr(self.cat), self.n, self.width, self.max_levels,
+        )
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in (self.ids, self.cnt, self.sig, self.orig))
+
+
+class Alphabet:
+    """Dense code units shared by both sides (<= 255 distinct symbols; the pad code is ``size``)."""
+
+    def __init__(self) -> None:
+        self._codes: Dict[str, int] = {}
+
+    def code(self, ch: str) -> int:
+        got = self._codes.get(ch)
+        if got is None:
+            got = len(self._codes)
+            if got >= 255:
+                raise NotImplementedError("more than 255 distinct code units in one grid")
+            self._codes[ch] = got
+        return got
+
+    @property
+    def size(self) -> int:
+        return max(1, len(self._codes))
+
+
+@dataclass
+class StrTable:
+    codes: torch.Tensor
+    len: torch.Tensor
+    orig: torch.Tensor
+    n: int
+    stride: int
+    alphabet: int
+    has_empty: bool
+
+    @classmethod
+    def from_codes(
+        cls, codes: np.ndarray, lengths: np.ndarray, alphabet: int, device, orig: Optional[np.ndarray] = None,
+        sort: bool = True,
+    ) -> "StrTable":
+        """From uint8 codes [n][64] (entries at positions >= len are ignored) and lengths."""
+        codes = np.asarray(codes, dtype=np.uint8)
+        lengths = np.asarray(lengths, dtype=np.int32)
+        n, stride = codes.shape
+        if stride != 64:
+            raise NotImplementedError("the Indel kernels hold one pattern in a single 64-bit word (<= 64 code units)")
+        if n and (lengths.max() > 64 or lengths.min() < 0):
+            raise NotImplementedError("string longer than 64 code units")
+        if not 1 <= alphabet <= 255:
+            raise ValueError("alphabet must be in [1, 255]")
+        codes = codes.copy()
+        codes[np.arange(64, dtype=np.int32)[None, :] >= lengths[:, None]] = alphabet
+        if n and int(codes.max()) > alphabet:
+            raise ValueError("code unit outside the alphabet")
+        perm = np.argsort(-lengths, kind="stable") if sort else np.arange(n)
+        base = np.arange(n, dtype=np.int32) if orig is None else np.asarray(orig, dtype=np.int32)
+        return cls(
+            codes=_dev(codes[perm], device),
+            len=_dev(lengths[perm], device),
+            orig=_dev(base[perm], device),
+            n=n,
+            stride=64,
+            alphabet=alphabet,
+            has_empty=bool(n and lengths.min() == 0),
+        )
+
+    @classmethod
+    def from_strings(cls, strings: Sequence[str], alphabet: Alphabet, device, sort: bool = True) -> "StrTable":
+        """From already pre-processed Python strings (see ``score_functions.default_process``).
+        Call ``alphabet.code`` for BOTH sides' strings before building either table, or build the
+        tables with ``encode_strings`` which does that."""
+        n = len(strings)
+        codes = np.zeros((n, 64), dtype=np.uint8)
+        lengths = np.zeros(n, dtype=np.int32)
+        for k, s in enumerate(strings):
+            if len(s) > 64:
+                raise NotImplementedError(
+                    f"string {k} has {len(s)} code units; the Indel kernels support <= 64 (one 64-bit word)"
+                )
+            lengths[k] = len(s)
+            for q, ch in enumerate(s):
+                codes[k, q] = alphabet.code(ch)
+        return cls.from_codes(codes, lengths, alphabet.size, device, sort=sort)
+
+    def struct(self) -> _lib.NsmStrTable:
+        return _lib.NsmStrTable(
+            self.codes.data_ptr(), self.len.data_ptr(), self.orig.data_ptr(), self.n, self.stride, self.alphabet
+        )
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in (self.codes, self.len, self.orig))
+
+
+def encode_strings(left: Sequence[str], right: Sequence[str], device):
+    """Both sides of a RAW fuzzy grid over one shared alphabet."""
+    alpha = Alphabet()
+    for s in list(left) + list(right):
+        for ch in s:
+            alpha.code(ch)
+    lt = StrTable.from_strings(left, alpha, device)
+    rt = StrTable.from_strings(right, alpha, device)
+    # both tables must agree on the alphabet size (it is also the pad code)
+    assert lt.alphabet == rt.alphabet == alpha.size
+    return lt, rt
+
+
+@dataclass
+class LevelItems:
+    """Items whose levels are consecutive rows of a (not length-sorted) ``StrTable``."""
+
+    first: torch.Tensor
+    nlev: torch.Tensor
+    orig: torch.Tensor
+    cat: Optional[torch.Tensor]
+    n: int
+
+    def struct(self) -> _lib.NsmLevelItems:
+        return _lib.NsmLevelItems(
+            self.first.data_ptr(), self.nlev.data_ptr(), self.orig.data_ptr(),
+            None if self.cat is None else self.cat.data_ptr(), self.n,
+        )
+
+
+def encode_level_strings(
+    left_items: Sequence[Sequence[str]], right_items: Sequence[Sequence[str]], device,
+    left_cat: Optional[np.ndarray] = None, right_cat: Optional[np.ndarray] = None,
+):
+    """Levels-mode fuzzy operands: every level of every item is one (pre-processed) string."""
+    alpha = Alphabet()
+    for items in (left_items, right_items):
+        for levels in items:
+            for s in levels:
+                for ch in s:
+                    alpha.code(ch)
+
+    def side(items, cat):
+        flat: List[str] = []
+        first = np.zeros(len(items), dtype=np.int32)
+        nlev = np.zeros(len(items), dtype=np.int32)
+        for k, levels in enumerate(items):
+            if len(levels) > MAX_LEVELS:
+                raise NotImplementedError(f"item {k} has {len(levels)} levels > {MAX_LEVELS}")
+            first[k] = len(flat)
+            nlev[k] = len(levels)
+            flat.extend(levels)
+        table = StrTable.from_strings(flat, alpha, device, sort=False)
+        # items sorted by level count (descending) so that a wavefront's items have similar depth
+        perm = np.argsort(-nlev, kind="stable")
+        li = LevelItems(
+            first=_dev(first[perm], device), nlev=_dev(nlev[perm], device),
+            orig=_dev(np.arange(len(items), dtype=np.int32)[perm], device),
+            cat=None if cat is None else _dev(np.asarray(cat, dtype=np.uint64)[perm], device), n=len(items),
+        )
+        return li, table
+
+    l_items, l_table = side(left_items, left_cat)
+    r_items, r_table = side(right_items, right_cat)
+    return l_items, l_table, r_items, r_table

@@ -1,0 +1,249 @@
+"""GPU parity of the four grid kernels, called through the C ABI (ctypes), against the oracle.
+
+Bar: Jaccard scores and hit indices bit-exact; Indel ratios within 1e-6 (they are in fact compared
+bit-exact too, the tolerance only documents what BASELINE.json's north_star asks for).
+"""
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FUZZY_TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+
+    return torch.device("cuda:0")
+
+
+def _same_hits(got, want, tol=0.0):
+    got_t = got.as_tuples()
+    assert len(got_t) == len(want), f"{len(got_t)} hits, oracle has {len(want)}"
+    if tol == 0.0:
+        assert got_t == want
+    else:
+        assert [(i, j) for _, i, j in got_t] == [(i, j) for _, i, j in want]
+        for (s, _, _), (w, _, _) in zip(got_t, want):
+            assert abs(s - w) <= tol
+
+
+def _rand_padded(rng, n, width, vocab, kmax, allow_empty):
+    ids = np.full((n, width), -1, dtype=np.int32)
+    for r in range(n):
+        k = rng.randint(0 if allow_empty else 1, kmax)
+        ids[r, :k] = rng.sample(range(vocab), k)
+    return ids
+
+
+@pytest.mark.parametrize("width,kmax,vocab", [(16, 16, 60), (16, 6, 25), (32, 32, 90), (64, 64, 200), (64, 40, 5000)])
+@pytest.mark.parametrize("prune", [False, True])
+def test_jaccard_raw_random(dev, width, kmax, vocab, prune):
+    from napkon_string_matching_amd import grid, tables
+    from oracle import native
+
+    rng = random.Random(width * 1000 + kmax)
+    left = _rand_padded(rng, 333, width, vocab, kmax, allow_empty=False)
+    right = _rand_padded(rng, 517, width, vocab, kmax, allow_empty=True)
+    lt = tables.SetTable.from_padded(left, "left", dev, width=width)
+    rt = tables.SetTable.from_padded(right, "right", dev, width=width)
+    for thr in (0.0, 0.05, 0.2, 1 / 3, 0.5, 0.75, 1.0, 1.5):
+        want = native.jaccard_raw(native.csr_from_padded(left), native.csr_from_padded(right), thr, cap=1 << 18)
+        got = grid.jaccard_raw_grid(lt, rt, thr, prune=prune, capacity=1 << 12)  # small: exercises the retry
+        _same_hits(got, want)
+
+
+def test_jaccard_raw_c2_shaped(dev):
+    """BASELINE configs[1] generator at 6000 x 5000 (the oracle finishes in seconds)."""
+    from napkon_string_matching_amd import grid, synthetic, tables
+    from oracle import native
+
+    left, right = synthetic.c2_corpus(6000, 5000)
+    lt = tables.SetTable.from_padded(left, "left", dev)
+    rt = tables.SetTable.from_padded(right, "right", dev)
+    want = native.jaccard_raw(native.csr_from_padded(left), native.csr_from_padded(right), 0.5)
+    assert len(want) >= 40  # the planted near-duplicates
+    for prune in (False, True):
+        _same_hits(grid.jaccard_raw_grid(lt, rt, 0.5, prune=prune), want)
+
+
+def test_jaccard_raw_edges(dev):
+    from napkon_string_matching_amd import grid, tables
+
+    one = np.array([[5, 7, -1, -1]], dtype=np.int32)
+    lt = tables.SetTable.from_padded(one, "left", dev)
+    rt = tables.SetTable.from_padded(np.array([[7, 5, 9, -1], [1, 2, 3, 4]], dtype=np.int32), "right", dev)
+    got = grid.jaccard_raw_grid(lt, rt, 0.5)
+    assert got.as_tuples() == [(2 / 3, 0, 0)]
+    # empty grid
+    empty = tables.SetTable.from_padded(np.zeros((0, 4), dtype=np.int32), "left", dev, width=16)
+    assert len(grid.jaccard_raw_grid(empty, rt, 0.0)) == 0
+    # empty-vs-empty is the reference's ZeroDivisionError (score_functions.py:13)
+    le = tables.SetTable.from_padded(np.array([[1, -1], [-1, -1]], dtype=np.int32), "left", dev)
+    re_ = tables.SetTable.from_padded(np.array([[-1, -1], [1, 2]], dtype=np.int32), "right", dev)
+    with pytest.raises(ZeroDivisionError):
+        grid.jaccard_raw_grid(le, re_, 0.1)
+    # one empty side only: scores 0.0, no error
+    ro = tables.SetTable.from_padded(np.array([[1, 2]], dtype=np.int32), "right", dev)
+    assert grid.jaccard_raw_grid(le, ro, 0.0).as_tuples() == [(0.5, 0, 0), (0.0, 1, 0)]
+    with pytest.raises(ValueError):
+        tables.SetTable.from_padded(np.array([[3, 3]], dtype=np.int32), "left", dev)
+    with pytest.raises(ValueError):
+        grid.jaccard_raw_grid(lt, lt, 0.5)  # both encoded as 'left': same padding value
+
+
+def _rand_strings(rng, n, alphabet, lo, hi):
+    out = []
+    for _ in range(n):
+        k = rng.randint(lo, hi)
+        out.append("".join(rng.choice(alphabet) for _ in range(k)))
+    return out
+
+
+@pytest.mark.parametrize("alphabet,lo,hi", [("ab", 0, 12), ("abcdefghijklmnopqrstuvwxyz0123456789 ", 0, 64),
+                                             ("abcdefgh", 30, 64), ("".join(chr(0x100 + k) for k in range(200)), 1, 64)])
+@pytest.mark.parametrize("prune", [False, True])
+def test_indel_raw_random(dev, alphabet, lo, hi, prune):
+    from napkon_string_matching_amd import grid, tables
+    from oracle import native
+
+    rng = random.Random(len(alphabet) * 100 + hi)
+    left = _rand_strings(rng, 150, alphabet, lo, hi)
+    right = _rand_strings(rng, 210, alphabet, lo, hi)
+    right[7] = left[3]
+    right[8] = left[4][:-1] + "a" if left[4] else "a"
+    lt, rt = tables.encode_strings(left, right, dev)
+    cp = lambda ss: native.csr([[ord(c) for c in s] for s in ss])
+    for thr in (0.0, 0.3, 0.5, 0.8, 1.0):
+        want = native.indel_raw(cp(left), cp(right), thr, cap=1 << 16)
+        got = grid.indel_raw_grid(lt, rt, thr, prune=prune, capacity=1 << 10)
+        _same_hits(got, want, FUZZY_TOL)
+        _same_hits(got, want)  # and in fact bit-exact
+
+
+def test_indel_raw_c3_shaped(dev):
+    from napkon_string_matching_amd import grid, synthetic, tables
+    from oracle import native
+
+    (lc, ll), (rc, rl) = synthetic.c3_corpus(1500, 1200)
+    lt = tables.StrTable.from_codes(lc, ll, len(synthetic.STRING_ALPHABET), dev)
+    rt = tables.StrTable.from_codes(rc, rl, len(synthetic.STRING_ALPHABET), dev)
+    want = native.indel_raw(native.csr_from_codes(lc, ll), native.csr_from_codes(rc, rl), 0.8)
+    assert len(want) >= 10
+    for prune in (False, True):
+        _same_hits(grid.indel_raw_grid(lt, rt, 0.8, prune=prune), want, FUZZY_TOL)
+
+
+def test_indel_known_answers(dev):
+    """Hand-derived ratios (fuzzy_match is parity unpinned: rapidfuzz is not available offline)."""
+    from napkon_string_matching_amd import grid, tables
+
+    pairs = [("kitten", "sitting", 8 / 13), ("lewenstein", "levenshtein", 18 / 21),
+             ("dialyse", "dialyse nach entlassung", 14 / 30), ("this is a test", "this is a test", 1.0)]
+    lt, rt = tables.encode_strings([p[0] for p in pairs], [p[1] for p in pairs], dev)
+    got = {(i, j): s for s, i, j in grid.indel_raw_grid(lt, rt, 0.0).as_tuples()}
+    assert len(got) == 16
+    for k, (_, _, want) in enumerate(pairs):
+        assert abs(got[(k, k)] - want) <= FUZZY_TOL
+    with pytest.raises(NotImplementedError):
+        tables.encode_strings(["x" * 65], ["y"], dev)
+
+
+def _nested_item(rng, vocab, max_levels, max_new, allow_empty_levels=False):
+    base, out = [], []
+    for _ in range(rng.randint(1, max_levels)):
+        new = rng.sample(range(vocab), rng.randint(0 if allow_empty_levels or base else 1, max_new))
+        for v in new:
+            if v not in base:
+                base.append(v)
+        out.append(list(base))
+    return out
+
+
+@pytest.mark.parametrize("vocab,max_levels,max_new", [(40, 5, 3), (200, 8, 2), (30, 20, 1), (300, 6, 9)])
+def test_jaccard_levels_random(dev, vocab, max_levels, max_new):
+    from napkon_string_matching_amd import _lib, grid, tables
+    from oracle import native
+
+    rng = random.Random(vocab + max_levels)
+    left = [_nested_item(rng, vocab, max_levels, max_new) for _ in range(230)]
+    right = [_nested_item(rng, vocab, max_levels, max_new) for _ in range(310)]
+    lcat = np.array([rng.choice([0, 1, 2, 3, 6]) for _ in left], dtype=np.uint64)
+    rcat = np.array([rng.choice([0, 1, 2, 4, 5]) for _ in right], dtype=np.uint64)
+    vocabulary = tables.Vocabulary()
+    width = tables.pick_width(max(len(it[-1]) for it in left + right))
+    lt = tables.SetTable.from_levels(left, "left", dev, vocabulary, width=width, categories=lcat)
+    rt = tables.SetTable.from_levels(right, "right", dev, vocabulary, width=width, categories=rcat)
+    for thr in (0.0, 0.1, 0.3, 0.6):
+        for mode in (_lib.CAT_NONE, _lib.CAT_INTERSECT, _lib.CAT_INTERSECT_OR_BOTH_EMPTY):
+            want = native.levels(False, left, right, thr, lcat, rcat, mode, cap=1 << 17)
+            got = grid.jaccard_levels_grid(lt, rt, thr, category_mode=mode, capacity=1 << 12)
+            _same_hits(got, want)
+
+
+def test_jaccard_levels_identical_items(dev):
+    """compare_terms on identical items gives 0.5 / 0.75 / 0.875 for 1 / 2 / 3 levels."""
+    from napkon_string_matching_amd import grid, tables
+
+    items = [[[1]], [[1], [1, 2]], [[1], [1, 2], [1, 2, 3]]]
+    v = tables.Vocabulary()
+    lt = tables.SetTable.from_levels(items, "left", dev, v)
+    rt = tables.SetTable.from_levels(items, "right", dev, v)
+    got = {(i, j): s for s, i, j in grid.jaccard_levels_grid(lt, rt, 0.0).as_tuples()}
+    assert got[(0, 0)] == 0.5 and got[(1, 1)] == 0.75 and got[(2, 2)] == 0.875
+    with pytest.raises(NotImplementedError):
+        tables.SetTable.from_levels([[[1, 2], [2, 3]]], "left", dev, v)  # not suffix-nested
+
+
+@pytest.mark.parametrize("max_levels", [1, 4, 9])
+def test_indel_levels_random(dev, max_levels):
+    from napkon_string_matching_amd import _lib, grid, tables
+    from oracle import native
+
+    rng = random.Random(77 + max_levels)
+    alphabet = "abcdefghij klm"
+
+    def item():
+        return [
+            "".join(rng.choice(alphabet) for _ in range(rng.randint(0, 40))).strip()
+            for _ in range(rng.randint(1, max_levels))
+        ]
+
+    left, right = [item() for _ in range(90)], [item() for _ in range(140)]
+    lcat = np.array([rng.choice([0, 1, 2, 3]) for _ in left], dtype=np.uint64)
+    rcat = np.array([rng.choice([0, 1, 2]) for _ in right], dtype=np.uint64)
+    li, ls, ri, rs = tables.encode_level_strings(left, right, dev, lcat, rcat)
+    cps = lambda items: [[[ord(c) for c in s] for s in it] for it in items]
+    for thr in (0.0, 0.25, 0.5):
+        for mode in (_lib.CAT_NONE, _lib.CAT_INTERSECT_OR_BOTH_EMPTY):
+            want = native.levels(True, cps(left), cps(right), thr, lcat, rcat, mode, cap=1 << 16)
+            got = grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, capacity=1 << 11)
+            _same_hits(got, want, FUZZY_TOL)
+            _same_hits(got, want)
+
+
+def test_sort_hits_large(dev):
+    """nsm_sort_hits beyond the rank-sort limit (bitonic passes) against numpy's lexsort."""
+    import torch
+
+    from napkon_string_matching_amd import grid
+
+    for n, cap in ((1000, 1 << 10), (5000, 1 << 13), (200_000, 1 << 18), (300_001, 300_001)):
+        rng = np.random.default_rng(n)
+        score = rng.integers(0, 50, n).astype(np.float64) / 49.0
+        i = rng.integers(0, 1000, n).astype(np.int32)
+        j = np.arange(n, dtype=np.int32)
+        rec = np.zeros((cap, 2), dtype=np.float64)
+        rec[:n, 0] = score
+        rec.view(np.int32).reshape(cap, 4)[:n, 2] = i
+        rec.view(np.int32).reshape(cap, 4)[:n, 3] = j
+        buf = grid.HitBuffer(cap, dev)
+        buf.records.copy_(torch.from_numpy(rec))
+        buf.count.fill_(n)
+        got = grid.sort_hits_device(buf, n)
+        order = np.lexsort((j, i, -score))
+        assert np.array_equal(got.score, score[order])
+        assert np.array_equal(got.i, i[order]) and np.array_equal(got.j, j[order])
