@@ -1,0 +1,332 @@
+#!/usr/bin/env python3
+"""Headline benchmark: pair-comparisons/sec of the all-pairs match loop on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3] [--no-cpu-baseline]
+
+N > 1 is launched by the driver as
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+(one process per GPU, RCCL).  One "step" = one pass of the hot path over one synthetic batch whose
+operand tables are already resident in HBM: zero the hit counter, score the whole N x M pair grid
+on the GPU (threshold test included), order the hits canonically and -- for N > 1 -- all-gather
+the (score, i, j) hits of every rank.  Left rows are block-sharded over the ranks, the right side is
+replicated; per-GPU work is fixed as N grows ("weak").
+
+Workload at N = 1 is BASELINE.json configs[1] ("c2": 50k x 50k token-id sets, mean 8 ids,
+intersection_vs_union, threshold 0.5); `--workload c3` runs configs[2] (200k x 200k strings,
+fuzzy_match, threshold 0.8).
+
+The JSON line carries, besides the driver's contract fields:
+  roofline      dominant kernel; achieved = algorithmic bytes (128 B per pair) per
+                launch / average kernel duration measured with HIP events on the launch stream
+  exhaustive    the same grid with the exact prune disabled (every pair's matrix evaluated)
+  cpu_baseline  the oracle's restatement of the reference's Python loop, 1 core, bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+for _p in (str(ROOT), str(ROOT / "napkon-string-matching_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+BYTES_PER_PAIR = 128  # two 64-byte operand rows
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=("c2", "c3"), default="c2")
+    ap.add_argument("--rows", type=int, default=0, help="override rows per side per GPU (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--capacity", type=int, default=1 << 16)
+    return ap.parse_args()
+
+
+class Workload:
+    """Operand tables in HBM + the launch closure of one workload."""
+
+    def __init__(self, name, rank, world, rows, device):
+        import numpy as np
+
+        from napkon_string_matching_amd import _lib, synthetic, tables
+
+        self.name = name
+        self.lib = _lib.load()
+        self.flag_prune = _lib.FLAG_PRUNE
+        if name == "c2":
+            n = rows or 50_000
+            m = rows or 50_000
+            self.threshold = 0.5
+            # global left corpus = world * n rows; this rank scores rows [rank*n, (rank+1)*n)
+            left = synthetic.token_sets(n, 1234 + 1000 * rank)
+            right = synthetic.token_sets(m, 5678)
+            if rank == 0:
+                right_planted = synthetic.plant_near_duplicate_sets(left, right, 5679)
+            else:
+                right_planted = None
+            self.host = (left, right, right_planted)
+            self.left_np = left
+            right = self._share_right(right_planted, right, device, world)
+            self.right_np = right
+            orig = np.arange(n, dtype=np.int32) + rank * n
+            self.left = tables.SetTable.from_padded(left, "left", device, orig=orig)
+            self.right = tables.SetTable.from_padded(right, "right", device)
+            self.launch_fn = self.lib.nsm_jaccard_raw_grid
+            self.kernel = "jaccard_raw_kernel<16>"
+            self.dtype = "int32"
+            self.label = f"C2: {n}x{m} token-id sets/GPU (Poisson(8) ids, W=16), intersection_vs_union RAW, threshold 0.5"
+        else:
+            n = rows or 200_000
+            m = rows or 200_000
+            self.threshold = 0.8
+            left = synthetic.strings(n, 1234 + 1000 * rank)
+            right = synthetic.strings(m, 5678)
+            if rank == 0:
+                rp = synthetic.plant_near_duplicate_strings(left, right, 5679)
+                packed = np.concatenate([rp[0], rp[1].astype(np.int32).view(np.uint8).reshape(m, 4)], axis=1)
+            else:
+                packed = None
+            packed = self._share_right(packed, np.zeros((m, 68), np.uint8), device, world)
+            rc, rl = packed[:, :64].copy(), packed[:, 64:].copy().view(np.int32).reshape(m)
+            self.left_np, self.right_np = left, (rc, rl)
+            orig = np.arange(n, dtype=np.int32) + rank * n
+            alpha = len(synthetic.STRING_ALPHABET)
+            self.left = tables.StrTable.from_codes(left[0], left[1], alpha, device, orig=orig)
+            self.right = tables.StrTable.from_codes(rc, rl, alpha, device)
+            self.launch_fn = self.lib.nsm_indel_raw_grid
+            self.kernel = "indel_raw_kernel"
+            self.dtype = "u64"
+            self.label = f"C3: {n}x{m} strings/GPU (len U[16,64], 37 symbols), fuzzy_match RAW, threshold 0.8"
+        self.n, self.m = n, m
+        self.ls, self.rs = self.left.struct(), self.right.struct()
+
+    @staticmethod
+    def _share_right(planted, like, device, world):
+        """The right side is replicated: rank 0's array is broadcast over RCCL."""
+        import torch
+
+        if world == 1:
+            return planted
+        import torch.distributed as dist
+
+        t = torch.from_numpy(planted if planted is not None else like.copy()).to(device)
+        dist.broadcast(t, src=0)
+        return t.cpu().numpy()
+
+    def launch(self, buf, stream, prune=True):
+        from napkon_string_matching_amd import _lib
+
+        flags = self.flag_prune if prune else 0
+        _lib.check(
+            self.launch_fn(self.ls, self.rs, float(self.threshold), flags, buf.records.data_ptr(), buf.capacity,
+                           buf.count.data_ptr(), stream),
+            self.kernel,
+        )
+
+
+def gather_hits(buf, world, device):
+    """all-gatherv of the (score, i, j) hits: counts first, then max-padded records (RCCL has no
+    native gatherv).  Returns (records [world][cap][2], counts[world])."""
+    import torch
+    import torch.distributed as dist
+
+    counts = torch.empty(world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(counts, buf.count)
+    out = torch.empty((world,) + tuple(buf.records.shape), dtype=buf.records.dtype, device=device)
+    dist.all_gather_into_tensor(out, buf.records)
+    return out, counts
+
+
+def cpu_baseline(work, budget_pairs):
+    """The oracle's Python restatement of the reference loop on a bounded sample, one core."""
+    import numpy as np
+
+    from napkon_string_matching_amd import synthetic
+    from oracle import compare as oc
+
+    if work.name == "c2":
+        side = int(budget_pairs ** 0.5)
+        left = synthetic.decode_sets(work.left_np[:side])
+        right = synthetic.decode_sets(work.right_np[:side])
+        t0 = time.perf_counter()
+        hits = oc.raw_grid_hits(left, right, "intersection_vs_union", work.threshold)
+        dt = time.perf_counter() - t0
+        sample = f"{side}x{side} sub-grid of the same corpus, set-based intersection_vs_union per pair (Python)"
+    else:
+        side = int(budget_pairs ** 0.5)
+        left = synthetic.decode_strings(work.left_np[0][:side], work.left_np[1][:side])
+        right = synthetic.decode_strings(work.right_np[0][:side], work.right_np[1][:side])
+        t0 = time.perf_counter()
+        hits = oc.raw_grid_hits(left, right, "fuzzy_match", work.threshold)
+        dt = time.perf_counter() - t0
+        sample = f"{side}x{side} sub-grid, pure-Python LCS Indel ratio per pair (NOT rapidfuzz)"
+    del hits, np
+    return {
+        "value": side * side / dt,
+        "unit": "pair-comparisons/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": sample,
+        "seconds": round(dt, 2),
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the match loop has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from napkon_string_matching_amd import grid
+
+    work = Workload(args.workload, rank, world, args.rows, device)
+    buf = grid.HitBuffer(args.capacity, device)
+    buf.scratch = torch.empty_like(buf.records)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    lib = work.lib
+
+    def step(prune=True):
+        buf.count.zero_()
+        work.launch(buf, stream, prune)
+        lib.nsm_sort_hits(buf.records.data_ptr(), buf.scratch.data_ptr(), buf.capacity, buf.count.data_ptr(), stream)
+        if world > 1:
+            return gather_hits(buf, world, device)
+        return None
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    def timed(steps, prune):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(prune)
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    for _ in range(args.warmup):
+        step(True)
+    dt = timed(args.steps, True)
+    n_hits = int(buf.count.item())
+    if n_hits > buf.capacity:
+        raise SystemExit(f"hit buffer overflow ({n_hits} > {buf.capacity}); raise --capacity")
+    pairs_per_step = work.n * work.m * world
+    value = pairs_per_step * args.steps / dt
+
+    # ---- per-kernel duration of the dominant kernel, HIP events on the launch stream
+    def kernel_ms(prune, reps):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        buf.count.zero_()
+        work.launch(buf, stream, prune)
+        torch.cuda.synchronize(device)
+        ev0.record()
+        for _ in range(reps):
+            work.launch(buf, stream, prune)
+        ev1.record()
+        torch.cuda.synchronize(device)
+        return ev0.elapsed_time(ev1) / reps
+
+    k_ms = kernel_ms(True, max(3, args.steps))
+    # exhaustive variant (prune off): fewer repetitions, it is the slow one
+    ex_steps = max(2, min(args.steps, 5))
+    step(False)
+    dt_ex = timed(ex_steps, False)
+    k_ms_ex = kernel_ms(False, ex_steps)
+
+    def roof(ms):
+        achieved = work.n * work.m * BYTES_PER_PAIR / (ms * 1e-3) / 1e9
+        return achieved
+
+    traffic = None
+    tfile = ROOT / "profiles" / f"traffic_{work.name}.json"
+    if tfile.exists():
+        try:
+            traffic = json.loads(tfile.read_text()).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    result = {
+        "metric": "pair-comparisons/sec (whole node), N x M all-pairs",
+        "value": value,
+        "unit": "pair-comparisons/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": work.dtype,
+        "data": "synthetic",
+        "config": {
+            "workload": work.label,
+            "score_func": "intersection_vs_union" if work.name == "c2" else "fuzzy_match",
+            "mode": "RAW",
+            "threshold": work.threshold,
+            "pairs_per_step": pairs_per_step,
+            "hits_per_rank": n_hits,
+            "sharding": f"left rows block-sharded over {world} rank(s), right replicated, hits all-gathered",
+            "exact_prune": True,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": work.kernel + " (exact prune on)",
+            "achieved": roof(k_ms),
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": roof(k_ms) / HBM_PEAK_GBPS,
+            "traffic": traffic,
+            "kernel_ms": k_ms,
+            "algorithmic_bytes_per_launch": work.n * work.m * BYTES_PER_PAIR,
+            "compulsory_hbm_bytes_per_launch": work.left.nbytes() + work.right.nbytes() + n_hits * 16,
+        },
+        "exhaustive": {
+            "note": "same grid, exact prune disabled: every pair's full comparison is evaluated",
+            "value": pairs_per_step * ex_steps / dt_ex,
+            "ms_per_step": dt_ex / ex_steps * 1e3,
+            "kernel_ms": k_ms_ex,
+            "achieved_GBps": roof(k_ms_ex),
+            "frac": roof(k_ms_ex) / HBM_PEAK_GBPS,
+        },
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(work, 6_000_000 if work.name == "c2" else 20_000)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
