@@ -1,0 +1,102 @@
+"""The score_func plugin module, MI355X edition.
+
+Same names, call convention and error behaviour as the reference's
+``napkon_string_matching/compare/score_functions.py`` (:6-27): callables
+``(left, right) -> float`` looked up BY NAME (types/comparable_data.py:150), plus
+``join_sorted``.  Each plugin has two faces:
+
+* calling it scores ONE pair -- as a 1 x 1 grid on the GPU, through the same kernels as the
+  batched path (there is no CPU implementation of the arithmetic in this package);
+* ``plugin.raw_grid(left_items, right_items, threshold)`` / the levels builders used by
+  ``ComparableData.gen_comparable`` score N x M pairs in one launch.
+
+``default_process`` / ``join_sorted`` are per-item string preparation and stay on the host; the
+reference re-does them for every pair (score_functions.py:24-25 inside the hot loop).
+"""
+from __future__ import annotations
+
+import re
+from typing import Iterable, List, Sequence, Union
+
+import torch
+
+from .. import grid, tables
+
+_NON_WORD = re.compile(r"\W", re.UNICODE)
+
+Operand = Union[str, List[str]]
+
+
+def _device():
+    if not torch.cuda.is_available():
+        from .._lib import NsmLibraryError
+
+        raise NsmLibraryError("score functions run on an MI355X (HIP device); there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def join_sorted(value: Sequence[str]) -> str:
+    """score_functions.py:16-17."""
+    return " ".join(sorted(value, key=str.lower))
+
+
+def default_process(text: str) -> str:
+    """rapidfuzz 2.x ``utils.default_process`` (applied by ``fuzz.QRatio`` by default in the
+    pinned 2.1 line): non-word code points -> blank, strip, lower-case."""
+    return _NON_WORD.sub(" ", text).strip().lower()
+
+
+def fuzzy_operand(value: Operand) -> str:
+    """What ``fuzzy_match`` feeds to the Indel ratio for one operand (score_functions.py:24-25
+    followed by QRatio's default processor)."""
+    return default_process(join_sorted(value) if isinstance(value, list) else value)
+
+
+def set_operand(value: Operand) -> Iterable[str]:
+    """What ``intersection_vs_union`` turns one operand into (score_functions.py:10-11)."""
+    return value if isinstance(value, list) else value.split()
+
+
+class _IntersectionVsUnion:
+    __name__ = "intersection_vs_union"
+    kind = "sets"
+
+    def __call__(self, left: Operand, right: Operand) -> float:
+        hits = self.raw_grid([left], [right], float("-inf"))
+        return float(hits.score[0])
+
+    @staticmethod
+    def raw_grid(left_items: Sequence[Operand], right_items: Sequence[Operand], threshold: float, device=None,
+                 prune: bool = True) -> grid.Hits:
+        dev = device or _device()
+        vocab = tables.Vocabulary()
+        l_rows = [set_operand(v) for v in left_items]
+        r_rows = [set_operand(v) for v in right_items]
+        width = tables.pick_width(
+            max((len(set(r)) for r in l_rows), default=1), max((len(set(r)) for r in r_rows), default=1)
+        )
+        lt = tables.SetTable.from_rows(l_rows, "left", dev, vocab, width=width)
+        rt = tables.SetTable.from_rows(r_rows, "right", dev, vocab, width=width)
+        return grid.jaccard_raw_grid(lt, rt, threshold, prune=prune)
+
+
+class _FuzzyMatch:
+    __name__ = "fuzzy_match"
+    kind = "strings"
+
+    def __call__(self, left: Operand, right: Operand) -> float:
+        hits = self.raw_grid([left], [right], float("-inf"))
+        return float(hits.score[0])
+
+    @staticmethod
+    def raw_grid(left_items: Sequence[Operand], right_items: Sequence[Operand], threshold: float, device=None,
+                 prune: bool = True) -> grid.Hits:
+        dev = device or _device()
+        lt, rt = tables.encode_strings(
+            [fuzzy_operand(v) for v in left_items], [fuzzy_operand(v) for v in right_items], dev
+        )
+        return grid.indel_raw_grid(lt, rt, threshold, prune=prune)
+
+
+intersection_vs_union = _IntersectionVsUnion()
+fuzzy_match = _FuzzyMatch()

@@ -1,0 +1,506 @@
+"""``ComparableData``: the cross-cohort N x M match loop with the reference's surface.
+
+Mirrors ``napkon_string_matching/types/comparable_data.py`` (:69-299, :452-574): same method names,
+keyword arguments, output columns, thresholds (``>=`` on doubles), exceptions and pair labels
+(``i*M + j`` after dropna / whitelist removal).  What differs is WHERE the work runs:
+
+* per ITEM (host, O(N + M)): dropna, whitelist removal, ``gen_comp_value`` levels, token -> id /
+  string encoding, category bit masks;
+* per PAIR (MI355X, one launch): the ``compare_terms`` sum over levels with the chosen score
+  function, the category predicate and the threshold (csrc/jaccard_levels_impl.hpp,
+  csrc/indel_levels.hip).  The reference's N*M-row ``merge(how="cross")`` frame (:191) is never built;
+* per HIT (host): the blacklist -- dropping a blacklisted pair before scoring (:195-204) equals
+  dropping it from the hit list -- and the output frame.
+
+The reference's per-pair exceptions only depend on per-item properties (a zero-level item ->
+``IndexError`` at :262, two empty level sets -> ``ZeroDivisionError`` at score_functions.py:13), so
+they are resolved on the host, in pair order, against the same blacklist / category filters.
+"""
+from __future__ import annotations
+
+import logging
+from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import pandas as pd
+
+from .. import _lib, grid, tables
+from ..compare import score_functions
+from .comparable import COLUMN_NAMES, IDENTIFIER, MATCH_SCORE, QUESTION_OUTPUT, Comparable
+from .mapping import Mapping
+
+logger = logging.getLogger(__name__)
+
+PREPARE_REMOVE_SYMBOLS = "!?,.()[]:;*"  # comparable_data.py:24
+COMP_COLUMN = "Compare"
+TERM = "Term"
+_INF = 1 << 30
+
+
+# =============================================================================== per item
+def flatten_list(list_) -> List[str]:
+    """One level of flattening (:567-574); a ``str`` is walked character by character."""
+    out: List[str] = []
+    for part in list_:
+        if isinstance(part, list):
+            out += part
+        else:
+            out.append(part)
+    return out
+
+
+class Tokenizer:
+    """The word tokenizer + stop-word list of ``tokenize`` (:287-299).
+
+    Upstream uses nltk punkt and nltk's German stop words; neither ships with this package (no
+    network at build time), so both are injectable.  The default (``str.split``, no stop words)
+    equals punkt on text made of plain alphanumeric words that are not stop words.
+    """
+
+    def __init__(self, word_tokenize: Callable[[str], Iterable[str]] = str.split, stop_words: Iterable[str] = ()):
+        self.word_tokenize = word_tokenize
+        self.stop_words = frozenset(stop_words)
+
+    @classmethod
+    def from_nltk(cls, language: str = "german") -> "Tokenizer":
+        from nltk.corpus import stopwords  # optional dependency
+        from nltk.tokenize import word_tokenize
+
+        return cls(word_tokenize, stopwords.words(language))
+
+    def __call__(self, parts) -> List[str]:
+        words = self.word_tokenize(" ".join(flatten_list(parts)))
+        kept = {w for w in words if w.casefold() not in self.stop_words and w not in PREPARE_REMOVE_SYMBOLS}
+        return sorted(kept, key=str.casefold)
+
+
+# =============================================================================== mappings
+def get_identifiers_from_mapping(mappings: Mapping, group: str) -> List[str]:
+    out: List[str] = []
+    for entry in mappings.values():
+        out += entry[group]
+    return out
+
+
+def flatten_mapping(left_group: str, right_group: str, mapping: Mapping) -> List[Tuple[str, str]]:
+    """Cartesian identifier pairs of every entry that lists both cohorts (:555-564)."""
+    return [(a, b) for lefts, rights in mapping.get_all_mapping_for_groups(left_group, right_group)
+            for a in lefts for b in rights]
+
+
+def _as_mapping(value) -> Mapping:
+    if value is None:
+        return Mapping()
+    if isinstance(value, Mapping):
+        return value
+    if isinstance(value, dict):
+        return Mapping(value)
+    if hasattr(value, "dict"):
+        return Mapping(value.dict())
+    raise TypeError("mappings must be a Mapping or a {uuid: {cohort: [identifiers]}} dict")
+
+
+# =============================================================================== categories
+class _Categories:
+    """Category columns of both sides as <= 64-bit masks + the device predicate mode."""
+
+    def __init__(self, left: Sequence, right: Sequence, first_left, first_right) -> None:
+        l_list, r_list = isinstance(first_left, list), isinstance(first_right, list)
+        if l_list and not r_list:
+            # :471 evaluates `x in set(y)` with x a list: hashing a list raises
+            raise TypeError("unhashable type: 'list'")
+        self.mode = _lib.CAT_INTERSECT_OR_BOTH_EMPTY if (l_list and r_list) else _lib.CAT_INTERSECT
+        self.scalar_scalar = not l_list and not r_list
+        bits: Dict[object, int] = {}
+
+        def mask(value, as_list: bool) -> Tuple[int, frozenset]:
+            labels = value if as_list else [value]
+            if as_list and not isinstance(value, list):
+                raise NotImplementedError("Category column mixes lists and scalars")
+            if not as_list and isinstance(value, list):
+                raise NotImplementedError("Category column mixes lists and scalars")
+            m = 0
+            keys = []
+            for lab in labels:
+                if isinstance(lab, float) and lab != lab:
+                    continue  # NaN never equals anything
+                keys.append(lab)
+                m |= 1 << bits.setdefault(lab, len(bits))
+            return m, frozenset(keys)
+
+        lm = [mask(v, l_list) for v in left]
+        rm = [mask(v, r_list) for v in right]
+        self.left_sets = [s for _, s in lm]
+        self.right_sets = [s for _, s in rm]
+        self.on_device = len(bits) <= 64
+        if self.on_device:
+            self.left_mask = np.array([m for m, _ in lm], dtype=np.uint64)
+            self.right_mask = np.array([m for m, _ in rm], dtype=np.uint64)
+
+    def match(self, i: int, j: int) -> bool:
+        a, b = self.left_sets[i], self.right_sets[j]
+        if a & b:
+            return True
+        return self.mode == _lib.CAT_INTERSECT_OR_BOTH_EMPTY and not a and not b
+
+
+# =============================================================================== the class
+class ComparableData:
+    """A cohort's items as a pandas frame plus the ``compare`` machinery.
+
+    Needs the columns ``Identifier``, ``Term`` and the compare column; ``Variable``, ``Sheet`` are
+    copied to the result when present; ``Category`` when ``filter_categories`` is on.
+    """
+
+    __column_mapping__: Dict[str, str] = {}
+    __category_column__ = "Category"
+    tokenizer: Tokenizer = Tokenizer()
+
+    def __init__(self, data=None) -> None:
+        if isinstance(data, ComparableData):
+            data = data._data
+        self.__dict__["_data"] = data if isinstance(data, pd.DataFrame) else pd.DataFrame(data)
+
+    # ---- thin frame wrapper (reference: types/data.py)
+    def __getattr__(self, name: str):
+        return getattr(self._data, name)
+
+    def __getitem__(self, item):
+        got = self._data[item]
+        return self.__class__(got) if isinstance(got, pd.DataFrame) else got
+
+    def __setitem__(self, item, value) -> None:
+        self._data[item] = value
+
+    def __len__(self) -> int:
+        return len(self._data)
+
+    def __repr__(self) -> str:
+        return repr(self._data)
+
+    def dataframe(self) -> pd.DataFrame:
+        return self._data
+
+    def dropna(self, *args, **kwargs) -> "ComparableData":
+        return self.__class__(self._data.dropna(*args, **kwargs))
+
+    def to_csv(self) -> str:
+        return self._data.to_csv(index=False)
+
+    def map_for_comparable(self) -> pd.DataFrame:
+        return self._data.rename(columns=self.__column_mapping__)
+
+    # ---- per item
+    @classmethod
+    def tokenize(cls, parts, language: str = "german") -> List[str]:
+        return cls.tokenizer(parts)
+
+    @classmethod
+    def gen_comp_value(cls, items) -> List[List[str]]:
+        """Level l = tokens of the last l+1 entries (:283-285)."""
+        return [cls.tokenize(items[-k:]) for k in range(1, len(items) + 1)]
+
+    @staticmethod
+    def gen_term(*items: str) -> List[str]:
+        return [item for item in items if item]
+
+    def get_existing_mapping_ids(self, group_name: str, mappings: Mapping) -> List[str]:
+        per_group = mappings.filter_by_group(group_name)
+        identifiers = list(self._data[IDENTIFIER])
+        return list({key for key, members in per_group.items() for ident in identifiers if ident in members})
+
+    def remove_existing_mappings(self, existing_mappings) -> None:
+        drop = set(existing_mappings)
+        self.__dict__["_data"] = self._data[[v not in drop for v in self._data[IDENTIFIER]]]
+
+    # ---- per pair (single): compare_terms as a 1 x 1 levels grid on the GPU
+    @classmethod
+    def compare_terms(cls, left: Sequence, right: Sequence, score_func) -> float:
+        """:248-265 for ONE pair.  ``score_func`` is one of this package's plugins (or its name)."""
+        plugin = _resolve_plugin(score_func)
+        if len(left) == 0 and len(right) == 0:
+            return 0
+        if len(left) == 0 or len(right) == 0:
+            raise IndexError("list index out of range")
+        if plugin.kind == "sets":
+            sets = lambda levels: [list(score_functions.set_operand(lv)) for lv in levels]
+            if min(_empty_step_limit(sets(left)), _empty_step_limit(sets(right))) >= 1:
+                raise ZeroDivisionError("division by zero")  # an empty-vs-empty level is visited
+        hits = _levels_grid(plugin, [list(left)], [list(right)], float("-inf"), None, None)
+        return float(hits.score[0])
+
+    # ---- the grid
+    def compare(
+        self,
+        other,
+        existing_mappings_whitelist=None,
+        existing_mappings_blacklist=None,
+        compare_column: str = None,
+        score_threshold: float = 0.1,
+        cached: bool = True,
+        cache_threshold: Optional[float] = None,
+        cache_dir=None,
+        identifier_column_left: Optional[str] = None,
+        identifier_column_right: Optional[str] = None,
+        *args,
+        **kwargs,
+    ) -> Comparable:
+        """:69-128.  Scores at ``cache_threshold or score_threshold``, keeps ``>= score_threshold``,
+        orders by score descending.  (The reference's compare cache is keyed by a hash that embeds
+        object addresses and so never hits; no cache file is read or written here.)"""
+        del cached, cache_dir
+        first = cache_threshold if cache_threshold else score_threshold
+        result = self.gen_comparable(
+            other,
+            existing_mappings_whitelist,
+            existing_mappings_blacklist,
+            *args,
+            score_threshold=first,
+            compare_column=compare_column,
+            identifier_column_left=identifier_column_left,
+            identifier_column_right=identifier_column_right,
+            **kwargs,
+        )
+        result = result[result.match_score >= score_threshold]
+        logger.info("got %i filtered entries", len(result))
+        result.sort_by_score()
+        return result
+
+    def gen_comparable(
+        self,
+        right,
+        existing_mappings_whitelist=None,
+        existing_mappings_blacklist=None,
+        score_func: str = None,
+        compare_column: str = None,
+        category_column: str = "Category",
+        score_threshold: float = 0.1,
+        left_name: str = None,
+        right_name: str = None,
+        filter_categories: bool = False,
+        identifier_column_left: Optional[str] = None,
+        identifier_column_right: Optional[str] = None,
+        *args,
+        **kwargs,
+    ) -> Comparable:
+        """:133-246 (steps 1-12 of SURVEY.md 3.2), the per-pair part on the GPU."""
+        plugin = getattr(score_functions, score_func)  # AttributeError for an unknown name (:150)
+        whitelist = _as_mapping(existing_mappings_whitelist)
+        blacklist = _as_mapping(existing_mappings_blacklist)
+        if not isinstance(right, ComparableData):
+            right = ComparableData(right)
+
+        left = self.dropna(subset=[compare_column])
+        right = right.dropna(subset=[compare_column])
+        logger.info(
+            "comparing number of items %i left, %i right, potential %s comparisons",
+            len(left), len(right), "{:,}".format(len(left) * len(right)),
+        )
+        remove_existing_mappings(left, right, left_name, right_name, whitelist)
+        logger.info("after removing existing whitelisted mappings: %i left, %i right", len(left), len(right))
+
+        lf, rf = left.map_for_comparable(), right.map_for_comparable()
+        lp, rp = left_name.title(), right_name.title()
+        n_l, n_r = len(lf), len(rf)
+
+        levels_l = [self.gen_comp_value(item) for item in lf[compare_column]]
+        levels_r = [self.gen_comp_value(item) for item in rf[compare_column]]
+        argument_l = [":".join(flatten_list(item)) for item in lf[TERM]]
+        argument_r = [":".join(flatten_list(item)) for item in rf[TERM]]
+
+        # ---- blacklist as position pairs
+        id_l = list(lf[identifier_column_left or IDENTIFIER])
+        id_r = list(rf[identifier_column_right or IDENTIFIER])
+        banned = _banned_positions(flatten_mapping(left_name, right_name, blacklist), id_l, id_r)
+        logger.info("remaining %s entries after removing blacklisted ones", "{:,}".format(n_l * n_r - len(banned)))
+
+        # ---- categories
+        cats: Optional[_Categories] = None
+        if filter_categories:
+            first = _first_surviving_pair(n_l, n_r, banned)
+            if first is None:
+                raise IndexError("single positional indexer is out-of-bounds")  # df.iloc[0] at :465
+            cl, cr = list(lf[category_column]), list(rf[category_column])
+            cats = _Categories(cl, cr, cl[first[0]], cr[first[1]])
+
+        def survives(i: int, j: int) -> bool:
+            return (i, j) not in banned and (cats is None or cats.match(i, j))
+
+        # ---- the reference's per-pair exceptions, in pair order
+        nlev_l = np.array([len(v) for v in levels_l], dtype=np.int64)
+        nlev_r = np.array([len(v) for v in levels_r], dtype=np.int64)
+        extra_hits: List[Tuple[int, int]] = []  # zero-level x zero-level pairs score 0
+        _raise_first_pair_error(
+            plugin.kind == "sets", levels_l, levels_r, nlev_l, nlev_r, n_r, survives, extra_hits
+        )
+
+        # ---- device grid over the items that have at least one level
+        keep_l = np.flatnonzero(nlev_l > 0)
+        keep_r = np.flatnonzero(nlev_r > 0)
+        logger.info("calculate score")
+        if keep_l.size and keep_r.size:
+            on_device = cats is not None and cats.on_device
+            hits = _levels_grid(
+                plugin,
+                [levels_l[k] for k in keep_l],
+                [levels_r[k] for k in keep_r],
+                score_threshold,
+                cats.left_mask[keep_l] if on_device else None,
+                cats.right_mask[keep_r] if on_device else None,
+                cats.mode if on_device else _lib.CAT_NONE,
+            )
+            hi, hj, hs = keep_l[hits.i], keep_r[hits.j], hits.score
+        else:
+            hi, hj, hs = np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.float64)
+        if extra_hits and 0.0 >= score_threshold:
+            ei = np.array([p[0] for p in extra_hits], dtype=np.int64)
+            ej = np.array([p[1] for p in extra_hits], dtype=np.int64)
+            hi, hj, hs = np.concatenate([hi, ei]), np.concatenate([hj, ej]), np.concatenate([hs, np.zeros(len(ei))])
+
+        # ---- per hit: blacklist (and categories when they could not go to the device)
+        if len(hs) and (banned or (cats is not None and not cats.on_device)):
+            ok = np.fromiter(
+                (
+                    (int(a), int(b)) not in banned and (cats is None or cats.on_device or cats.match(int(a), int(b)))
+                    for a, b in zip(hi, hj)
+                ),
+                dtype=bool, count=len(hs),
+            )
+            hi, hj, hs = hi[ok], hj[ok], hs[ok]
+
+        # ---- output frame in the reference's row order (pair label ascending)
+        label = hi.astype(np.int64) * n_r + hj.astype(np.int64)
+        order = np.argsort(label, kind="stable")
+        hi, hj, hs, label = hi[order], hj[order], hs[order], label[order]
+        lf = lf.assign(**{COMP_COLUMN: levels_l, QUESTION_OUTPUT: argument_l})
+        rf = rf.assign(**{COMP_COLUMN: levels_r, QUESTION_OUTPUT: argument_r})
+        out = {}
+        for frame, prefix, rows in ((lf, lp, hi), (rf, rp, hj)):
+            for col in frame.columns:  # survivors keep the frame's column order (:236-240)
+                if col in COLUMN_NAMES:
+                    out[prefix + col] = frame[col].to_numpy()[rows] if len(rows) else frame[col].to_numpy()[:0]
+        out[MATCH_SCORE] = hs
+        table = pd.DataFrame(out, index=pd.Index(label))
+        logger.info("got %s entries", "{:,}".format(len(table)))
+        return Comparable(data=table, left_name=lp, right_name=rp)
+
+
+# =============================================================================== helpers
+def remove_existing_mappings(
+    left: ComparableData, right: ComparableData, left_name: str, right_name: str, existing_mappings: Mapping
+) -> None:
+    """:493-513 -- drop items already linked by a whitelist entry; skipped as a whole on KeyError."""
+    try:
+        left_ids = left.get_existing_mapping_ids(left_name, existing_mappings)
+        right_ids = right.get_existing_mapping_ids(right_name, existing_mappings)
+    except KeyError:
+        return
+    used = set(left_ids) & set(right_ids)
+    filtered = existing_mappings.get_filtered(used)
+    left.remove_existing_mappings(get_identifiers_from_mapping(filtered, left_name))
+    right.remove_existing_mappings(get_identifiers_from_mapping(filtered, right_name))
+
+
+def _resolve_plugin(score_func):
+    if isinstance(score_func, str):
+        return getattr(score_functions, score_func)
+    if score_func in (score_functions.intersection_vs_union, score_functions.fuzzy_match):
+        return score_func
+    raise NotImplementedError(
+        "only this package's score functions (intersection_vs_union, fuzzy_match) have a device implementation"
+    )
+
+
+def _banned_positions(pairs, id_l: Sequence, id_r: Sequence) -> set:
+    if not pairs:
+        return set()
+    pos_l: Dict[object, List[int]] = {}
+    pos_r: Dict[object, List[int]] = {}
+    for k, v in enumerate(id_l):
+        pos_l.setdefault(v, []).append(k)
+    for k, v in enumerate(id_r):
+        pos_r.setdefault(v, []).append(k)
+    out = set()
+    for a, b in pairs:
+        for i in pos_l.get(a, ()):
+            for j in pos_r.get(b, ()):
+                out.add((i, j))
+    return out
+
+
+def _first_surviving_pair(n_l: int, n_r: int, banned: set) -> Optional[Tuple[int, int]]:
+    for i in range(n_l):
+        for j in range(n_r):
+            if (i, j) not in banned:
+                return i, j
+    return None
+
+
+def _empty_step_limit(levels: Sequence[Sequence]) -> int:
+    """Largest step s >= 1 at which the item presents an EMPTY level (levels are nested, so the
+    empty ones are a prefix): _INF when every level is empty, otherwise (#empty levels) - 1."""
+    empty = 0
+    for lv in levels:
+        if len(lv) == 0:
+            empty += 1
+        else:
+            break
+    return _INF if empty == len(levels) else empty - 1
+
+
+def _raise_first_pair_error(is_sets, levels_l, levels_r, nlev_l, nlev_r, n_r, survives, extra_hits) -> None:
+    zero_l, zero_r = np.flatnonzero(nlev_l == 0), np.flatnonzero(nlev_r == 0)
+    candidates: List[Tuple[int, int, type]] = []
+    for i in zero_l:
+        for j in range(len(nlev_r)):
+            if nlev_r[j] == 0:
+                extra_hits.append((int(i), j))
+            else:
+                candidates.append((int(i), j, IndexError))
+    for j in zero_r:
+        for i in range(len(nlev_l)):
+            if nlev_l[i] != 0:
+                candidates.append((i, int(j), IndexError))
+    if is_sets:
+        lim_l = [(_empty_step_limit(v) if len(v) else -1) for v in levels_l]
+        lim_r = [(_empty_step_limit(v) if len(v) else -1) for v in levels_r]
+        sus_l = [i for i, v in enumerate(lim_l) if v >= 1]
+        sus_r = [j for j, v in enumerate(lim_r) if v >= 1]
+        for i in sus_l:
+            for j in sus_r:
+                candidates.append((i, j, ZeroDivisionError))
+    best = None
+    for i, j, exc in candidates:
+        if survives(i, j):
+            lab = i * n_r + j
+            if best is None or lab < best[0]:
+                best = (lab, exc)
+    extra_hits[:] = [p for p in extra_hits if survives(*p)]
+    if best is not None:
+        if best[1] is IndexError:
+            raise IndexError("list index out of range")
+        raise ZeroDivisionError("division by zero")
+
+
+def _levels_grid(plugin, levels_l, levels_r, threshold, cat_l, cat_r, cat_mode=_lib.CAT_NONE) -> grid.Hits:
+    """Encode both sides' levels for ``plugin`` and run the levels grid on the current device."""
+    import torch
+
+    if not torch.cuda.is_available():
+        raise _lib.NsmLibraryError("the match loop runs on an MI355X (HIP device); there is no CPU fallback")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    if plugin.kind == "sets":
+        vocab = tables.Vocabulary()
+        as_sets = lambda items: [[list(score_functions.set_operand(lv)) for lv in it] for it in items]
+        sl, sr = as_sets(levels_l), as_sets(levels_r)
+        width = tables.pick_width(
+            max((len(set(it[-1])) for it in sl if it), default=1), max((len(set(it[-1])) for it in sr if it), default=1)
+        )
+        lt = tables.SetTable.from_levels(sl, "left", dev, vocab, width=width, categories=cat_l)
+        rt = tables.SetTable.from_levels(sr, "right", dev, vocab, width=width, categories=cat_r)
+        if len(vocab) >= 1 << 25:
+            raise NotImplementedError("vocabulary of 2^25 or more distinct tokens")
+        return grid.jaccard_levels_grid(lt, rt, threshold, category_mode=cat_mode)
+    prep = lambda items: [[score_functions.fuzzy_operand(lv) for lv in it] for it in items]
+    li, ls, ri, rs = tables.encode_level_strings(prep(levels_l), prep(levels_r), dev, cat_l, cat_r)
+    return grid.indel_levels_grid(li, ls, ri, rs, threshold, category_mode=cat_mode)
