@@ -24,7 +24,7 @@ from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple
 import numpy as np
 import pandas as pd
 
-from .. import _lib, grid, tables
+from .. import _lib, distributed, grid, tables
 from ..compare import score_functions
 from .comparable import COLUMN_NAMES, IDENTIFIER, MATCH_SCORE, QUESTION_OUTPUT, Comparable
 from .mapping import Mapping
@@ -337,6 +337,11 @@ class ComparableData:
         # ---- device grid over the items that have at least one level
         keep_l = np.flatnonzero(nlev_l > 0)
         keep_r = np.flatnonzero(nlev_r > 0)
+        rank, world_size = distributed.world()
+        if world_size > 1:  # left rows block-sharded over the ranks, right side replicated
+            row_lo, row_hi = distributed.shard_bounds(n_l, rank, world_size)
+            keep_l = keep_l[(keep_l >= row_lo) & (keep_l < row_hi)]
+            extra_hits = [p for p in extra_hits if row_lo <= p[0] < row_hi]
         logger.info("calculate score")
         if keep_l.size and keep_r.size:
             on_device = cats is not None and cats.on_device
@@ -367,6 +372,9 @@ class ComparableData:
                 dtype=bool, count=len(hs),
             )
             hi, hj, hs = hi[ok], hj[ok], hs[ok]
+
+        if world_size > 1:  # the one exchange step: all-gatherv of the hits
+            hs, hi, hj = distributed.all_gather_hits(hs, hi, hj)
 
         # ---- output frame in the reference's row order (pair label ascending)
         label = hi.astype(np.int64) * n_r + hj.astype(np.int64)

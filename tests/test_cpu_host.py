@@ -1,0 +1,213 @@
+"""CPU-only checks (run with -m "not gpu"): the C ABI library loads and exports every symbol that
+include/nsm_hip.h declares, the host encoders / containers behave, the product refuses to score
+without a GPU, and the N > 1 exchange step works with gloo at world_size 2."""
+import ctypes
+import os
+import re
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_library_exports_every_declared_symbol():
+    from napkon_string_matching_amd import _lib
+
+    header = (ROOT / "include" / "nsm_hip.h").read_text()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(nsm_[a-z_]+)\s*\(", header, re.M))
+    assert declared == set(_lib.EXPORTS)
+    if not _lib.LIB_PATH.exists():
+        pytest.skip("libnsm_hip.so not built (run __graft_entry__.build())")
+    lib = _lib.load()
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.nsm_abi_version() == _lib.ABI_VERSION
+    # struct layouts must match the header (sizes on LP64)
+    assert ctypes.sizeof(_lib.NsmHit) == 16
+    assert ctypes.sizeof(_lib.NsmSetTable) == 7 * 8 + 3 * 4 + 4
+    assert ctypes.sizeof(_lib.NsmStrTable) == 3 * 8 + 3 * 4 + 4
+    assert ctypes.sizeof(_lib.NsmLevelItems) == 4 * 8 + 4 + 4
+
+
+def test_argument_validation_without_gpu():
+    """Bad arguments are rejected by the launcher before anything touches a device."""
+    from napkon_string_matching_amd import _lib
+
+    if not _lib.LIB_PATH.exists():
+        pytest.skip("libnsm_hip.so not built")
+    lib = _lib.load()
+    a = _lib.NsmSetTable(None, None, None, None, None, None, None, 3, 16, 0)
+    b = _lib.NsmSetTable(None, None, None, None, None, None, None, 3, 32, 0)
+    cnt = ctypes.c_ulonglong(0)
+    rc = lib.nsm_jaccard_raw_grid(a, b, 0.5, 0, None, 0, ctypes.addressof(cnt), None)
+    assert rc == 10001 and b"width" in lib.nsm_last_error()
+    s = _lib.NsmStrTable(None, None, None, 1, 128, 10)
+    rc = lib.nsm_indel_raw_grid(s, s, 0.5, 0, None, 0, ctypes.addressof(cnt), None)
+    assert rc == 10002
+    with pytest.raises(NotImplementedError):
+        _lib.check(rc, "nsm_indel_raw_grid")
+
+
+def test_no_cpu_fallback():
+    import torch
+
+    from napkon_string_matching_amd import _lib
+    from napkon_string_matching_amd.compare.score_functions import fuzzy_match, intersection_vs_union
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.NsmLibraryError):
+        intersection_vs_union(["a"], ["a"])
+    with pytest.raises(_lib.NsmLibraryError):
+        fuzzy_match("a", "a")
+
+
+def test_product_never_imports_oracle():
+    pkg = ROOT / "napkon-string-matching_amd"
+    for path in pkg.rglob("*.py"):
+        text = path.read_text()
+        assert "oracle" not in text.replace("oracle/", "").replace("oracle.score_functions", "") or "import oracle" not in text, path
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), path
+
+
+def test_set_table_encoding_cpu():
+    from napkon_string_matching_amd import tables
+
+    ids = np.array([[5, -1, 9, 2], [-1, -1, -1, -1], [7, 8, -1, -1]], dtype=np.int32)
+    t = tables.SetTable.from_padded(ids, "right", "cpu")
+    assert t.width == 16 and t.n == 3 and t.has_empty
+    assert t.cnt.tolist() == [3, 2, 0] and t.orig.tolist() == [0, 2, 1]
+    row0 = t.ids[0].tolist()
+    assert row0[:3] == [5, 9, 2] and set(row0[3:]) == {-2}
+    assert tables.SetTable.from_padded(ids, "left", "cpu").ids[2].tolist() == [-1] * 16
+    sig = tables.signatures(np.array([[1, 1 + (1 << 20)]], dtype=np.int32), np.array([2], np.int32))
+    assert bin(int(sig[0])).count("1") in (1, 2)
+    with pytest.raises(NotImplementedError):
+        tables.pick_width(65)
+    v = tables.Vocabulary()
+    lv = tables.SetTable.from_levels([[["b"], ["b", "a"], ["c", "a", "b"]], [["z"]]], "left", "cpu", v)
+    assert lv.nlev.tolist() == [3, 1] and lv.plen[0, :4].tolist() == [1, 2, 3, 3] and lv.plen[1, :2].tolist() == [1, 1]
+    assert lv.ids[0, :3].tolist() == [v.id("b"), v.id("a"), v.id("c")]
+
+
+def test_str_table_encoding_cpu():
+    from napkon_string_matching_amd import tables
+
+    lt, rt = tables.encode_strings(["abc", "", "ba"], ["cab"], "cpu")
+    assert lt.alphabet == rt.alphabet == 3 and lt.has_empty
+    assert lt.len.tolist() == [3, 2, 0] and lt.orig.tolist() == [0, 2, 1]
+    assert lt.codes[0, :4].tolist() == [0, 1, 2, 3]  # pad code == alphabet size
+    li, ls, ri, rs = tables.encode_level_strings([["a", "ab"], ["b"]], [["c"]], "cpu")
+    assert li.nlev.tolist() == [2, 1] and li.first.tolist() == [0, 2] and ls.n == 3 and rs.n == 1
+
+
+def test_containers():
+    from napkon_string_matching_amd.types.comparable import Comparable
+    from napkon_string_matching_amd.types.comparable_data import ComparableData, flatten_mapping
+    from napkon_string_matching_amd.types.mapping import Mapping
+
+    frame = pd.DataFrame({"HapIdentifier": ["h0", "h1", "h2"], "PopIdentifier": ["p0", "p1", "p2"],
+                          "HapVariable": ["a", "b", "c"], "PopVariable": ["x", "y", "z"],
+                          "MatchScore": [0.5, 0.75, 0.5]}, index=[7, 3, 2])
+    c = Comparable(frame, "Hap", "Pop")
+    assert list(c.match_variable) == ["a", "b", "c"] and list(c.variable) == ["x", "y", "z"]  # match_* -> LEFT
+    c.sort_by_score()
+    assert list(c.dataframe().index) == [3, 2, 7]
+    again = Comparable(data={"left_name": "Hap", "right_name": "Pop", "data": c.dataframe().to_dict(orient="records")})
+    assert list(again.match_score) == [0.75, 0.5, 0.5]
+    with pytest.raises(AttributeError):
+        Comparable(data={"x": 1})
+    m = Mapping({"u1": {"hap": ["h1", "h2"], "pop": ["p1"]}, "u2": {"hap": ["h3"], "suep": ["s1"]}})
+    assert flatten_mapping("hap", "pop", m) == [("h1", "p1"), ("h2", "p1")]
+    with pytest.raises(KeyError):
+        m.filter_by_group("pop")
+    assert ComparableData.gen_comp_value(["a b", "c"]) == [["c"], ["a", "b", "c"]]
+    assert ComparableData.gen_comp_value("abca") == [["a"], ["a", "c"], ["a", "b", "c"], ["a", "b", "c"]]
+
+
+def test_matcher_pair_enumeration(monkeypatch):
+    from napkon_string_matching_amd.matcher import Matcher
+    from napkon_string_matching_amd.types.comparable_data import ComparableData
+
+    calls = []
+
+    def fake_compare(self, other, **kwargs):
+        calls.append((kwargs["left_name"], kwargs["right_name"], kwargs["compare_column"], kwargs["score_threshold"]))
+        return "result"
+
+    monkeypatch.setattr(ComparableData, "compare", fake_compare)
+    q = {name: ComparableData(pd.DataFrame({"Identifier": [name]})) for name in ("suep", "Hap", "pop")}
+    cfg = {"matching": {"score_threshold": 0.7, "compare_column": "Term", "score_func": "fuzzy_match",
+                        "variable_score_threshold": 0.9}}
+    m = Matcher(None, cfg, questionnaires=q, gecco=ComparableData(pd.DataFrame({"Identifier": ["g"]})))
+    m.match_questionnaires()
+    assert list(m.results.results) == ["Hap vs suep", "pop vs suep", "Hap vs pop"] or sorted(m.results.results) == [
+        "Hap vs pop", "Hap vs suep", "pop vs suep"]
+    assert {c[:2] for c in calls} == {("Hap", "suep"), ("Hap", "pop"), ("pop", "suep")}
+    calls.clear()
+    m.clear_results()
+    m.match_questionnaires_variables()
+    assert all(c[2] == "Variable" and c[3] == 0.9 for c in calls) and len(calls) == 3
+    assert all(k.startswith("var_") for k in m.results.results)
+    m.match_gecco_with_questionnaires()
+    assert {"gecco vs suep", "gecco vs Hap", "gecco vs pop"} <= set(m.results.results)
+
+
+def test_shard_bounds():
+    from napkon_string_matching_amd.distributed import shard_bounds
+
+    for n in (0, 1, 7, 8, 9, 1000):
+        for w in (1, 2, 3, 8):
+            blocks = [shard_bounds(n, r, w) for r in range(w)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+            assert max(hi - lo for lo, hi in blocks) <= -(-n // w) if n else True
+
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, {pkg!r})
+import numpy as np, torch, torch.distributed as dist
+from napkon_string_matching_amd.distributed import all_gather_hits, shard_bounds, world
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, size = world()
+rng = np.random.default_rng(5)
+n = 41
+score = rng.integers(0, 6, n) / 5.0
+i = rng.integers(0, 20, n); j = np.arange(n)
+lo, hi = shard_bounds(20, rank, size)
+mine = (i >= lo) & (i < hi)
+s, gi, gj = all_gather_hits(score[mine], i[mine], j[mine])
+order = np.lexsort((j, i, -score))
+assert np.array_equal(s, score[order]) and np.array_equal(gi, i[order]) and np.array_equal(gj, j[order]), rank
+# an empty contribution from one rank must work too
+s2, _, _ = all_gather_hits(score[:0] if rank else score, i[:0] if rank else i, j[:0] if rank else j)
+assert len(s2) == n
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_all_gather_hits_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(pkg=str(ROOT / "napkon-string-matching_amd")))
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=240)
+        assert p.returncode == 0, out.decode()
