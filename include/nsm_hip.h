@@ -52,8 +52,14 @@ typedef struct nsm_hit {
 /* Token-id set table of one side, rows sorted by `cnt` DESCENDING (the encoder does this).
  *   ids   device int32 [n][width]  unique ids >= 0, unused slots padded (left: -1, right: -2)
  *   cnt   device int32 [n]         number of ids in the row (RAW) / in the item's largest level
- *   sig   device uint64[n]         64-bit signature: OR of 1 << ((id * 0x9E3779B1u) >> 26)
+ *   sig   device uint64[n]         signature word: bits 0..57 = OR over the row's ids of
+ *                                  1 << ((((id * 0x9E3779B1u) >> 16) & 0xffff) * 58 >> 16); bits 58..63 =
+ *                                  min(63, cnt - popcount(bits 0..57)) (ids that collided inside the row)
+ *   sig2  device uint64[n]         second, independent signature word (multiplier 0xC2B2AE35u);
+ *                                  optional (NULL: the prune has one stage)
  *   orig  device int32 [n]         caller's row id reported in hits
+ *   size_start device int32[width+2]  rows with cnt == width - c are [size_start[c], size_start[c+1])
+ *                                  (size_start[0] = 0, size_start[width+1] = n); required by the RAW grid
  *   -- levels mode only (NULL in RAW mode) --
  *   nlev  device int32 [n]         number of levels L (>= 1)
  *   plen  device uint8 [n][max_levels]  level l = the first plen[l] ids of the row (non-decreasing)
@@ -63,7 +69,9 @@ typedef struct nsm_set_table {
   const int32_t* ids;
   const int32_t* cnt;
   const uint64_t* sig;
+  const uint64_t* sig2;
   const int32_t* orig;
+  const int32_t* size_start;
   const int32_t* nlev;
   const uint8_t* plen;
   const uint64_t* cat;

@@ -5,8 +5,10 @@
 //
 // The number of hits lives in device memory (the grids append with an atomic counter), so the
 // launch geometry comes from `capacity` and every kernel reads the count itself:
-//   * capacity <= 128 Ki records: rank sort -- each record counts its predecessors in one pass over
-//     LDS-staged tiles and is scattered to scratch[rank]; one launch, no inter-block dependency;
+//   * up to 2048 live records (the common case): ONE workgroup sorts 128-bit integer keys
+//     (~score bits, i, j) with a bitonic network in LDS and writes the records back in place;
+//   * up to 128 Ki records of capacity: rank sort -- each record counts its predecessors in one pass
+//     over LDS-staged tiles and is scattered to scratch[rank]; no inter-block dependency;
 //   * larger: bitonic network in global memory, "flip" form (all comparators point the same way),
 //     which needs no padding to a power of two; passes beyond the live count exit immediately.
 #include "nsm_common.hpp"
@@ -25,12 +27,71 @@ __device__ __forceinline__ unsigned long long live_count(const unsigned long lon
   return c < capacity ? c : capacity;
 }
 
+constexpr int kSmallSortMax = 2048;
+constexpr int kSmallSortThreads = 1024;
+
+// Order-preserving integer image of a double, inverted: larger score -> smaller key.
+__device__ __forceinline__ unsigned long long score_key(double score) {
+  const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(score));
+  const unsigned long long asc = bits ^ ((bits >> 63) ? ~0ull : (1ull << 63));
+  return ~asc;
+}
+
+__global__ __launch_bounds__(kSmallSortThreads) void small_sort_kernel(
+    nsm_hit* __restrict__ hits, unsigned long long capacity, const unsigned long long* __restrict__ count) {
+  __shared__ unsigned long long key_hi[kSmallSortMax];
+  __shared__ unsigned long long key_lo[kSmallSortMax];
+  const unsigned long long n64 = live_count(count, capacity);
+  if (n64 < 2 || n64 > kSmallSortMax) return;
+  const int n = static_cast<int>(n64);
+  int p = 2;
+  while (p < n) p <<= 1;
+  for (int t = threadIdx.x; t < p; t += kSmallSortThreads) {
+    if (t < n) {
+      const nsm_hit h = hits[t];
+      key_hi[t] = score_key(h.score);
+      key_lo[t] = (static_cast<unsigned long long>(static_cast<uint32_t>(h.i) ^ 0x80000000u) << 32) |
+                  (static_cast<uint32_t>(h.j) ^ 0x80000000u);
+    } else {
+      key_hi[t] = ~0ull;  // padding sorts last
+      key_lo[t] = ~0ull;
+    }
+  }
+  __syncthreads();
+  for (int k = 2; k <= p; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < (p >> 1); t += kSmallSortThreads) {
+        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // element with bit j clear
+        const int hi = lo | j;
+        const bool up = (lo & k) == 0;
+        const unsigned long long ah = key_hi[lo], al = key_lo[lo], bh = key_hi[hi], bl = key_lo[hi];
+        const bool a_gt_b = ah > bh || (ah == bh && al > bl);
+        if (a_gt_b == up) {
+          key_hi[lo] = bh; key_lo[lo] = bl;
+          key_hi[hi] = ah; key_lo[hi] = al;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int t = threadIdx.x; t < n; t += kSmallSortThreads) {
+    const unsigned long long asc = ~key_hi[t];
+    const unsigned long long bits = asc ^ ((asc >> 63) ? (1ull << 63) : ~0ull);
+    nsm_hit h;
+    h.score = __longlong_as_double(static_cast<long long>(bits));
+    h.i = static_cast<int32_t>(static_cast<uint32_t>(key_lo[t] >> 32) ^ 0x80000000u);
+    h.j = static_cast<int32_t>(static_cast<uint32_t>(key_lo[t]) ^ 0x80000000u);
+    hits[t] = h;
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void rank_sort_kernel(const nsm_hit* __restrict__ hits,
                                                            nsm_hit* __restrict__ out,
                                                            unsigned long long capacity,
                                                            const unsigned long long* __restrict__ count) {
   __shared__ nsm_hit tile[kBlock];
   const unsigned long long n = live_count(count, capacity);
+  if (n <= kSmallSortMax) return;  // small_sort_kernel's job
   const unsigned long long base = static_cast<unsigned long long>(blockIdx.x) * kBlock;
   if (base >= n) return;  // whole block
   const unsigned long long idx = base + threadIdx.x;
@@ -55,6 +116,7 @@ __global__ __launch_bounds__(kBlock) void copy_hits_kernel(const nsm_hit* __rest
                                                            unsigned long long capacity,
                                                            const unsigned long long* __restrict__ count) {
   const unsigned long long n = live_count(count, capacity);
+  if (n <= kSmallSortMax) return;  // sorted in place by small_sort_kernel
   for (unsigned long long idx = static_cast<unsigned long long>(blockIdx.x) * kBlock + threadIdx.x; idx < n;
        idx += static_cast<unsigned long long>(gridDim.x) * kBlock)
     dst[idx] = src[idx];
@@ -101,6 +163,8 @@ extern "C" int nsm_sort_hits(nsm_hit* hits, nsm_hit* scratch, uint64_t capacity,
       return NSM_E_BADARG;
     }
     const unsigned blocks = static_cast<unsigned>((capacity + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(small_sort_kernel, dim3(1), dim3(kSmallSortThreads), 0, s, hits, capacity, hit_count);
+    if (capacity <= kSmallSortMax) return hip_status(hipGetLastError(), "nsm_sort_hits (small)");
     hipLaunchKernelGGL(rank_sort_kernel, dim3(blocks), dim3(kBlock), 0, s, hits, scratch, capacity, hit_count);
     hipLaunchKernelGGL(copy_hits_kernel, dim3(blocks < 1024 ? blocks : 1024), dim3(kBlock), 0, s, scratch, hits,
                        capacity, hit_count);

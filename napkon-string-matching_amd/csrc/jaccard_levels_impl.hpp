@@ -68,7 +68,7 @@ __device__ __forceinline__ void levels_wave_rows(
     bool ok = valid;
     if (p.cat_mode != NSM_CAT_NONE) ok = ok && category_match(lcat[i], catr, p.cat_mode);
     bool want = ok;
-    if (!p.emit_all) want = ok && ((lsig[i] & sr) != 0ull);  // no common signature bit -> score 0
+    if (!p.emit_all) want = ok && ((lsig[i] & sr) != 0ull);  // no common hash bit -> score 0
     if (!__any(want)) continue;
 
     const int nl = lcnt[i];
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(kBlock) void jaccard_levels_kernel(
     r[4 * q + 3] = (v.w << 6) | (4 * q + 3);
   }
   const int nrj = valid ? rcnt[jc] : 0;
-  const uint64_t sr = valid ? rsig[jc] : 0ull;
+  const uint64_t sr = valid ? (rsig[jc] & ((1ull << 58) - 1)) : 0ull;  // hash bits only
   const uint64_t catr = (p.cat_mode != NSM_CAT_NONE) ? rcat[jc] : 0ull;
   const int lr = rnlev[jc];
   const int jorig = rorig[jc];

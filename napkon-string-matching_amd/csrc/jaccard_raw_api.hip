@@ -30,7 +30,8 @@ extern "C" int nsm_jaccard_raw_grid(const nsm_set_table* left, const nsm_set_tab
     return NSM_E_BADARG;
   }
   if (left->n == 0 || right->n == 0) return 0;
-  if (!left->ids || !left->cnt || !left->orig || !right->ids || !right->cnt || !right->orig) {
+  if (!left->ids || !left->cnt || !left->orig || !left->size_start || !right->ids || !right->cnt ||
+      !right->orig) {
     set_error("nsm_jaccard_raw_grid: table has a null column");
     return NSM_E_BADARG;
   }

@@ -13,8 +13,10 @@
 //   * threshold test on integers: hit  <=>  matches >= kmin[|A|+|B|], with kmin computed by the
 //     launcher with the very double division/compare the reference performs; the double score is
 //     only computed for hits;
-//   * optional exact prune: |A n B| <= popcount(sigA & sigB) + min(cA, cB) (64-bit id signatures,
-//     c = in-row signature collisions); a wave skips the matrix when no lane can reach kmin.
+//   * optional exact prune, two stages: |A n B| <= popcount(hashbits(A) & hashbits(B)) + cA with 58
+//     hash bits per signature word (cA = in-row collisions, kept in the word's top 6 bits); a wave
+//     skips the matrix unless some lane can reach kmin under two independent signatures;
+//   * exact size filter: a whole size class is skipped when kmin > min(|A|, |B|) for every lane.
 #pragma once
 #include "nsm_common.hpp"
 
@@ -31,59 +33,61 @@ struct JacRawScalars {
   uint8_t kmin[2 * W + 4];  // indexed by |A|+|B|
 };
 
+// Wave-uniform value -> VGPR.  On gfx950 a VALU op with an SGPR source issues at half rate
+// (4.5 vs 2.4 cycles per wave64 v_xor_b32, profiles/r01_valu_issue_rates_gfx950.txt), so an id that
+// is XORed against NB registers is first broadcast with ONE v_mov_b32.
+__device__ __forceinline__ uint32_t to_vgpr(uint32_t uniform) {
+  uint32_t v;
+  asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(uniform));
+  return v;
+}
+
+// hipcc re-associates nested umin() into v_min_u32 pairs and turns umin(x, 1) into cmp + cndmask;
+// the matrix wants exactly one v_min3_u32 per two id pairs, so it is spelled out.
+__device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t d;
+  asm("v_min3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ uint32_t min3u_one(uint32_t a, uint32_t b) {
+  uint32_t d;
+  asm("v_min3_u32 %0, %1, %2, 1" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+
 // Number of left ids (out of NL, padding included) that do NOT occur in the lane's right row.
+// Per id: 1 v_mov + NB v_xor (full rate) + NB/2 v_min3 (half rate) + 1 v_add; the constant 1 rides
+// in the first min3, so m ends as 0 (found) or 1 (not found) without a separate clamp.
 template <int W, int NL, int NB>
 __device__ __forceinline__ int nonmatches(const int32_t* __restrict__ lrow, const uint32_t (&r)[W]) {
   static_assert(NB >= 2 && NB % 2 == 0, "right class must be even");
-  int nm = 0;
+  uint32_t l[NL];
+#pragma unroll
+  for (int a = 0; a < NL; ++a) l[a] = static_cast<uint32_t>(lrow[a]);  // one s_load_dwordxN
+  uint32_t nm = 0;
 #pragma unroll
   for (int a = 0; a < NL; ++a) {
-    const uint32_t la = static_cast<uint32_t>(lrow[a]);  // SGPR
-    uint32_t m = min(la ^ r[0], la ^ r[1]);
+    const uint32_t la = to_vgpr(l[a]);
+    uint32_t m = min3u_one(la ^ r[0], la ^ r[1]);
 #pragma unroll
-    for (int b = 2; b < NB; b += 2) m = min(m, min(la ^ r[b], la ^ r[b + 1]));  // v_min3_u32
-    nm += static_cast<int>(min(m, 1u));
+    for (int b = 2; b < NB; b += 2) m = min3u(m, la ^ r[b], la ^ r[b + 1]);
+    nm += m;
   }
-  return nm;
+  return static_cast<int>(nm);
 }
 
-template <int W, int NB, bool PRUNE>
-__device__ __forceinline__ void wave_rows(const int32_t* __restrict__ lids,
-                                          const int32_t* __restrict__ lcnt,
-                                          const uint64_t* __restrict__ lsig,
-                                          const int32_t* __restrict__ lorig,
-                                          nsm_hit* __restrict__ hits, unsigned long long cap,
-                                          unsigned long long* __restrict__ count,
-                                          const uint32_t (&r)[W], int nrj, uint64_t sr, int jorig,
-                                          bool valid, int i0, int i1, const uint8_t* s_kmin) {
-  constexpr int NLS = W / 4;  // left size classes: NLS, 2 NLS, 3 NLS, W
-  int prev_nl = -1;
-  int need = kNever;
-  const int extra_r = nrj - __popcll(sr);
-  for (int i = i0; i < i1; ++i) {
-    const int nl = lcnt[i];  // wave-uniform -> scalar load
-    if (nl != prev_nl) {       // rows are sorted by size: at most W+1 changes per chunk
-      prev_nl = nl;
-      need = valid ? s_kmin[nl + nrj] : kNever;
-    }
-    if (PRUNE) {
-      // |A n B| <= popcount(sigA & sigB) + min(cA, cB), c = ids of the row that share a signature
-      // bit with an earlier id of the same row (|row| - popcount(sig)): common ids that collide
-      // inside both rows are the only ones the AND can miss.
-      const uint64_t sl = lsig[i];
-      const int bound = __popcll(sl & sr) + min(nl - __popcll(sl), extra_r);
-      if (!__any(bound >= need)) continue;
-    }
-    const int32_t* __restrict__ lrow = lids + static_cast<size_t>(i) * W;
-    const int cls = (nl + NLS - 1) / NLS;
-    int k;
-    switch (cls) {
-      case 0: k = 0; break;
-      case 1: k = NLS - nonmatches<W, NLS, NB>(lrow, r); break;
-      case 2: k = 2 * NLS - nonmatches<W, 2 * NLS, NB>(lrow, r); break;
-      case 3: k = 3 * NLS - nonmatches<W, 3 * NLS, NB>(lrow, r); break;
-      default: k = W - nonmatches<W, W, NB>(lrow, r); break;
-    }
+// Score the left rows [a, b) -- all of size `nl`, size class NL -- against the lane's right row.
+template <int W, int NL, int NB, bool PRUNE>
+__device__ __forceinline__ void class_rows(const int32_t* __restrict__ lids,
+                                           const uint64_t* __restrict__ lsig,
+                                           const uint64_t* __restrict__ lsig2,
+                                           const int32_t* __restrict__ lorig,
+                                           nsm_hit* __restrict__ hits, unsigned long long cap,
+                                           unsigned long long* __restrict__ count,
+                                           const uint32_t (&r)[W], int nrj, uint64_t sr, uint64_t sr2,
+                                           int jorig, int a, int b, int nl, int need) {
+  auto exact_row = [&](int i) {
+    const int k = NL - nonmatches<W, NL, NB>(lids + static_cast<size_t>(i) * W, r);
     const bool hit = k >= need;
     if (__any(hit)) {
       if (hit) {
@@ -91,15 +95,118 @@ __device__ __forceinline__ void wave_rows(const int32_t* __restrict__ lids,
         emit_hit(hits, cap, count, score, lorig[i], jorig);
       }
     }
+  };
+  if constexpr (PRUNE) {
+    // |A n B| <= popcount(hashbits(A) & hashbits(B)) + cA.  A signature word holds 58 hash bits and,
+    // in its top 6 bits, cA = the ids of the row that share a hash bit with an earlier id of the
+    // same row (|A| - popcount(hashbits)): common ids that collide inside the row are the only ones
+    // the AND can miss.  (sr, sr2 come with their top 6 bits cleared.)
+    // Per row: 2 v_and + 2 v_bcnt (chained accumulate, seeded with the scalar cA) + v_cmp +
+    // v_addc (shifts the verdict into a per-lane bit mask) = 6 VALU and 1 SALU; the scalar unit is
+    // shared by the CU's 4 SIMDs, so the verdicts are NOT collected with s_cselect/s_or.
+    constexpr int BATCH = 8;
+    auto bound_of = [&](uint64_t sl, uint64_t srm) {
+      const int extra_l = static_cast<int>(sl >> 58);  // SALU
+      const uint32_t lo = static_cast<uint32_t>(sl) & static_cast<uint32_t>(srm);
+      const uint32_t hi = static_cast<uint32_t>(sl >> 32) & static_cast<uint32_t>(srm >> 32);
+      int bound;
+      asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(bound) : "v"(lo), "s"(extra_l));
+      asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(bound) : "v"(hi), "v"(bound));
+      return bound;
+    };
+    auto second_stage = [&](int i) {
+      return lsig2 == nullptr || __any(bound_of(lsig2[i], sr2) >= need);
+    };
+    int i = a;
+    if (i + BATCH <= b) {
+      // software pipeline: the signatures of batch k+1 are in flight while batch k is tested
+      uint64_t cur[BATCH];
+#pragma unroll
+      for (int q = 0; q < BATCH; ++q) cur[q] = lsig[i + q];  // one s_load_dwordx16
+      for (; i + BATCH <= b; i += BATCH) {
+        const int inext = (i + 2 * BATCH <= b) ? i + BATCH : i;  // last batch re-reads itself
+        uint64_t nxt[BATCH];
+#pragma unroll
+        for (int q = 0; q < BATCH; ++q) nxt[q] = lsig[inext + q];
+        uint32_t cand = 0;  // per lane: bit (BATCH-1-q) = row q may reach the threshold
+#pragma unroll
+        for (int q = 0; q < BATCH; ++q) {
+          const int bound = bound_of(cur[q], sr);
+          asm("v_cmp_ge_i32 vcc, %1, %2\n\ts_nop 1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+              : "+v"(cand) : "v"(bound), "v"(need) : "vcc");
+        }
+        if (__any(cand != 0)) {  // rare
+          for (int q = 0; q < BATCH; ++q) {  // ONE copy of the matrix body (I-cache footprint)
+            if (__any((cand >> (BATCH - 1 - q)) & 1u)) {
+              // second stage: an independent signature must agree before the matrix is paid for
+              if (second_stage(i + q)) exact_row(i + q);
+            }
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < BATCH; ++q) cur[q] = nxt[q];
+      }
+    }
+    for (; i < b; ++i) {
+      if (__any(bound_of(lsig[i], sr) >= need) && second_stage(i)) exact_row(i);
+    }
+  } else {
+    for (int i = a; i < b; ++i) exact_row(i);
+  }
+}
+
+template <int W, int NB, bool PRUNE>
+__device__ __forceinline__ void wave_rows(const int32_t* __restrict__ lids,
+                                          const int32_t* __restrict__ lcnt,
+                                          const int32_t* __restrict__ lstart,
+                                          const uint64_t* __restrict__ lsig,
+                                          const uint64_t* __restrict__ lsig2,
+                                          const int32_t* __restrict__ lorig,
+                                          nsm_hit* __restrict__ hits, unsigned long long cap,
+                                          unsigned long long* __restrict__ count,
+                                          const uint32_t (&r)[W], int nrj, uint64_t sr, uint64_t sr2,
+                                          int jorig, bool valid, int i0, int i1, const uint8_t* s_kmin) {
+  constexpr int NLS = W / 4;  // left size classes: NLS, 2 NLS, 3 NLS, W
+  // rows are sorted by size (descending): rows of size W - c are [lstart[c], lstart[c + 1]); the
+  // chunk [i0, i1) only touches the sizes between its first and its last row
+  const int c_first = W - lcnt[i0];
+  const int c_last = W - lcnt[i1 - 1];
+  for (int c = c_first; c <= c_last; ++c) {
+    const int a = max(i0, lstart[c]);
+    const int b = min(i1, lstart[c + 1]);
+    if (a >= b) continue;
+    const int nl = W - c;
+    const int need = valid ? s_kmin[nl + nrj] : kNever;
+    // exact size filter: a pair can only reach the threshold if kmin <= min(|A|, |B|)
+    if (!__any(need <= min(nl, nrj))) continue;
+#define NSM_ROWS(NL) \
+  class_rows<W, NL, NB, PRUNE>(lids, lsig, lsig2, lorig, hits, cap, count, r, nrj, sr, sr2, jorig, a, b, nl, need)
+    switch ((nl + NLS - 1) / NLS) {
+      case 0: {  // empty left sets: no common id, hit only when kmin == 0 (threshold <= 0)
+        const bool hit = need == 0;
+        if (__any(hit)) {
+          for (int i = a; i < b; ++i)
+            if (hit) emit_hit(hits, cap, count, 0.0 / static_cast<double>(nrj), lorig[i], jorig);
+        }
+        break;
+      }
+      case 1: NSM_ROWS(NLS); break;
+      case 2: NSM_ROWS(2 * NLS); break;
+      case 3: NSM_ROWS(3 * NLS); break;
+      default: NSM_ROWS(W); break;
+    }
+#undef NSM_ROWS
   }
 }
 
 template <int W, bool PRUNE>
 __global__ __launch_bounds__(kBlock) void jaccard_raw_kernel(
     const int32_t* __restrict__ lids, const int32_t* __restrict__ lcnt,
-    const uint64_t* __restrict__ lsig, const int32_t* __restrict__ lorig,
-    const int32_t* __restrict__ rids, const int32_t* __restrict__ rcnt,
-    const uint64_t* __restrict__ rsig, const int32_t* __restrict__ rorig,
+    const int32_t* __restrict__ lstart, const uint64_t* __restrict__ lsig,
+    const uint64_t* __restrict__ lsig2,
+    const int32_t* __restrict__ lorig, const int32_t* __restrict__ rids,
+    const int32_t* __restrict__ rcnt, const uint64_t* __restrict__ rsig,
+    const uint64_t* __restrict__ rsig2, const int32_t* __restrict__ rorig,
     nsm_hit* __restrict__ hits, unsigned long long* __restrict__ count, const JacRawScalars<W> p) {
   __shared__ uint8_t s_kmin[2 * W + 4];
   for (int t = threadIdx.x; t < 2 * W + 4; t += kBlock) s_kmin[t] = p.kmin[t];
@@ -123,7 +230,10 @@ __global__ __launch_bounds__(kBlock) void jaccard_raw_kernel(
     r[4 * q + 3] = v.w;
   }
   const int nrj = valid ? rcnt[jc] : 0;
-  const uint64_t sr = (PRUNE && valid) ? rsig[jc] : 0ull;
+  constexpr uint64_t kHashBits = (1ull << 58) - 1;  // the top 6 bits of a signature word hold cA
+  const uint64_t sr = (PRUNE && valid) ? (rsig[jc] & kHashBits) : 0ull;
+  const uint64_t sr2 = (PRUNE && valid && rsig2 != nullptr) ? (rsig2[jc] & kHashBits) : 0ull;
+  if (rsig2 == nullptr) lsig2 = nullptr;
   const int jorig = rorig[jc];
   const int nbmax = wave_first(nrj);  // sorted descending: lane 0 holds the tile's largest set
 
@@ -132,17 +242,20 @@ __global__ __launch_bounds__(kBlock) void jaccard_raw_kernel(
 
   constexpr int NBS = W / 8;  // right size classes: NBS, 2 NBS, ..., W
   const int cls = (nbmax + NBS - 1) / NBS;
+#define NSM_WAVE(K) \
+  wave_rows<W, (K) * NBS, PRUNE>(lids, lcnt, lstart, lsig, lsig2, lorig, hits, p.cap, count, r, nrj, sr, sr2, jorig, valid, i0, i1, s_kmin)
   switch (cls) {
     case 0:
-    case 1: wave_rows<W, 1 * NBS, PRUNE>(lids, lcnt, lsig, lorig, hits, p.cap, count, r, nrj, sr, jorig, valid, i0, i1, s_kmin); break;
-    case 2: wave_rows<W, 2 * NBS, PRUNE>(lids, lcnt, lsig, lorig, hits, p.cap, count, r, nrj, sr, jorig, valid, i0, i1, s_kmin); break;
-    case 3: wave_rows<W, 3 * NBS, PRUNE>(lids, lcnt, lsig, lorig, hits, p.cap, count, r, nrj, sr, jorig, valid, i0, i1, s_kmin); break;
-    case 4: wave_rows<W, 4 * NBS, PRUNE>(lids, lcnt, lsig, lorig, hits, p.cap, count, r, nrj, sr, jorig, valid, i0, i1, s_kmin); break;
-    case 5: wave_rows<W, 5 * NBS, PRUNE>(lids, lcnt, lsig, lorig, hits, p.cap, count, r, nrj, sr, jorig, valid, i0, i1, s_kmin); break;
-    case 6: wave_rows<W, 6 * NBS, PRUNE>(lids, lcnt, lsig, lorig, hits, p.cap, count, r, nrj, sr, jorig, valid, i0, i1, s_kmin); break;
-    case 7: wave_rows<W, 7 * NBS, PRUNE>(lids, lcnt, lsig, lorig, hits, p.cap, count, r, nrj, sr, jorig, valid, i0, i1, s_kmin); break;
-    default: wave_rows<W, 8 * NBS, PRUNE>(lids, lcnt, lsig, lorig, hits, p.cap, count, r, nrj, sr, jorig, valid, i0, i1, s_kmin); break;
+    case 1: NSM_WAVE(1); break;
+    case 2: NSM_WAVE(2); break;
+    case 3: NSM_WAVE(3); break;
+    case 4: NSM_WAVE(4); break;
+    case 5: NSM_WAVE(5); break;
+    case 6: NSM_WAVE(6); break;
+    case 7: NSM_WAVE(7); break;
+    default: NSM_WAVE(8); break;
   }
+#undef NSM_WAVE
 }
 
 // kmin[s] = least k with double(k)/double(s-k) >= threshold (k <= s/2), kNever if none.
@@ -191,10 +304,12 @@ int launch_raw(const nsm_set_table* l, const nsm_set_table* r, double threshold,
   const bool prune = (flags & NSM_FLAG_PRUNE) && l->sig && r->sig;
   if (prune)
     hipLaunchKernelGGL((jaccard_raw_kernel<W, true>), grid, dim3(kBlock), 0, stream, l->ids, l->cnt,
-                       l->sig, l->orig, r->ids, r->cnt, r->sig, r->orig, hits, hit_count, p);
+                       l->size_start, l->sig, l->sig2, l->orig, r->ids, r->cnt, r->sig, r->sig2, r->orig, hits,
+                       hit_count, p);
   else
     hipLaunchKernelGGL((jaccard_raw_kernel<W, false>), grid, dim3(kBlock), 0, stream, l->ids, l->cnt,
-                       l->sig, l->orig, r->ids, r->cnt, r->sig, r->orig, hits, hit_count, p);
+                       l->size_start, l->sig, l->sig2, l->orig, r->ids, r->cnt, r->sig, r->sig2, r->orig, hits,
+                       hit_count, p);
   return hip_status(hipGetLastError(), "jaccard_raw_kernel launch");
 }
 

@@ -23,7 +23,9 @@ class NsmSetTable(ctypes.Structure):
         ("ids", ctypes.c_void_p),
         ("cnt", ctypes.c_void_p),
         ("sig", ctypes.c_void_p),
+        ("sig2", ctypes.c_void_p),
         ("orig", ctypes.c_void_p),
+        ("size_start", ctypes.c_void_p),
         ("nlev", ctypes.c_void_p),
         ("plen", ctypes.c_void_p),
         ("cat", ctypes.c_void_p),

@@ -29,6 +29,7 @@ WIDTHS = (16, 32, 64)
 MAX_LEVELS = 64
 LEFT_PAD, RIGHT_PAD = -1, -2
 _GOLDEN = np.uint32(0x9E3779B1)
+_GOLDEN2 = np.uint32(0xC2B2AE35)
 
 
 def pick_width(*max_counts: int) -> int:
@@ -41,13 +42,24 @@ def pick_width(*max_counts: int) -> int:
     )
 
 
-def signatures(ids: np.ndarray, cnt: np.ndarray) -> np.ndarray:
-    """64-bit row signature: bit ((id * 0x9E3779B1) >> 26) for every id of the row."""
+def signatures(ids: np.ndarray, cnt: np.ndarray, multiplier: np.uint32 = _GOLDEN) -> np.ndarray:
+    """Signature word per row (include/nsm_hip.h): 58 hash bits, and in the top 6 bits the number
+    of ids that collided with an earlier id of the same row (saturating at 63)."""
     n, w = ids.shape
+    if not n:
+        return np.zeros(0, np.uint64)
     valid = np.arange(w, dtype=np.int32)[None, :] < cnt[:, None]
-    h = ((ids.astype(np.uint32) * _GOLDEN) >> np.uint32(26)).astype(np.uint64)
-    bits = np.where(valid, np.uint64(1) << h, np.uint64(0))
-    return np.bitwise_or.reduce(bits, axis=1) if n else np.zeros(0, np.uint64)
+    h16 = ((ids.astype(np.uint32) * multiplier) >> np.uint32(16)) & np.uint32(0xFFFF)
+    pos = ((h16.astype(np.uint64) * np.uint64(58)) >> np.uint64(16)).astype(np.uint64)
+    bits = np.where(valid, np.uint64(1) << pos, np.uint64(0))
+    word = np.bitwise_or.reduce(bits, axis=1)
+    pop = np.zeros(n, dtype=np.int64)
+    tmp = word.copy()
+    for _ in range(58):
+        pop += (tmp & np.uint64(1)).astype(np.int64)
+        tmp >>= np.uint64(1)
+    extra = np.minimum(63, cnt.astype(np.int64) - pop).astype(np.uint64)
+    return word | (extra << np.uint64(58))
 
 
 def _dev(array: np.ndarray, device) -> torch.Tensor:
@@ -81,6 +93,8 @@ class SetTable:
     width: int
     n: int
     has_empty: bool
+    sig2: Optional[torch.Tensor] = None
+    size_start: Optional[torch.Tensor] = None
     nlev: Optional[torch.Tensor] = None
     plen: Optional[torch.Tensor] = None
     cat: Optional[torch.Tensor] = None
@@ -201,15 +215,21 @@ class SetTable:
         perm = np.argsort(-cnt, kind="stable")  # size descending, ties by input order
         base = np.arange(n, dtype=np.int32) if orig is None else np.asarray(orig, dtype=np.int32)
         ids, cnt_s = ids[perm], cnt[perm]
+        # rows of size (width - c) occupy [size_start[c], size_start[c + 1]) in the sorted table
+        per_size = np.bincount(cnt_s, minlength=width + 1)[: width + 1]
+        size_start = np.zeros(width + 2, dtype=np.int32)
+        size_start[1:] = np.cumsum(per_size[::-1])
         return cls(
             ids=_dev(ids, device),
             cnt=_dev(cnt_s, device),
             sig=_dev(signatures(ids, cnt_s), device),
+            sig2=_dev(signatures(ids, cnt_s, _GOLDEN2), device),
             orig=_dev(base[perm], device),
             side=side,
             width=width,
             n=n,
             has_empty=bool(n and cnt.min() == 0),
+            size_start=_dev(size_start, device),
             nlev=None if nlev is None else _dev(nlev[perm], device),
             plen=None if plen is None else _dev(plen[perm], device),
             cat=None if cat is None else _dev(np.asarray(cat, dtype=np.uint64)[perm], device),
@@ -222,7 +242,9 @@ class SetTable:
             return None if t is None else t.data_ptr()
 
         return _lib.NsmSetTable(
-            ptr(self.ids), ptr(self.cnt), ptr(self.sig), ptr(self.orig), ptr(self.nlev), ptr(self.plen),
+            ptr(self.ids), ptr(self.cnt), ptr(self.sig), ptr(self.sig2), ptr(self.orig), ptr(self.size_start),
+            ptr(self.nlev),
+            ptr(self.plen),
             ptr(self.cat), self.n, self.width, self.max_levels,
         )
 

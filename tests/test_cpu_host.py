@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.nsm_abi_version() == _lib.ABI_VERSION
     # struct layouts must match the header (sizes on LP64)
     assert ctypes.sizeof(_lib.NsmHit) == 16
-    assert ctypes.sizeof(_lib.NsmSetTable) == 7 * 8 + 3 * 4 + 4
+    assert ctypes.sizeof(_lib.NsmSetTable) == 9 * 8 + 3 * 4 + 4
     assert ctypes.sizeof(_lib.NsmStrTable) == 3 * 8 + 3 * 4 + 4
     assert ctypes.sizeof(_lib.NsmLevelItems) == 4 * 8 + 4 + 4
 
@@ -48,8 +48,8 @@ def test_argument_validation_without_gpu():
     if not _lib.LIB_PATH.exists():
         pytest.skip("libnsm_hip.so not built")
     lib = _lib.load()
-    a = _lib.NsmSetTable(None, None, None, None, None, None, None, 3, 16, 0)
-    b = _lib.NsmSetTable(None, None, None, None, None, None, None, 3, 32, 0)
+    a = _lib.NsmSetTable(None, None, None, None, None, None, None, None, None, 3, 16, 0)
+    b = _lib.NsmSetTable(None, None, None, None, None, None, None, None, None, 3, 32, 0)
     cnt = ctypes.c_ulonglong(0)
     rc = lib.nsm_jaccard_raw_grid(a, b, 0.5, 0, None, 0, ctypes.addressof(cnt), None)
     assert rc == 10001 and b"width" in lib.nsm_last_error()
@@ -89,6 +89,8 @@ def test_set_table_encoding_cpu():
     t = tables.SetTable.from_padded(ids, "right", "cpu")
     assert t.width == 16 and t.n == 3 and t.has_empty
     assert t.cnt.tolist() == [3, 2, 0] and t.orig.tolist() == [0, 2, 1]
+    ss = t.size_start.tolist()
+    assert len(ss) == 18 and ss[0] == 0 and ss[-1] == 3 and ss[13] == 0 and ss[14] == 1 and ss[15] == 2 and ss[16] == 2
     row0 = t.ids[0].tolist()
     assert row0[:3] == [5, 9, 2] and set(row0[3:]) == {-2}
     assert tables.SetTable.from_padded(ids, "left", "cpu").ids[2].tolist() == [-1] * 16
