@@ -4,17 +4,21 @@
 //
 // Mapping to CDNA4
 //   * bit-parallel LCS (Hyyro / Allison-Dix):  V = ~0;  per text symbol c:  U = V & PM[c];
-//     V = (V + U) | (V - U);  LCS = popcount(~V).  Strings of <= 64 code units -> one 64-bit word;
-//   * one LANE owns one right string (the "text") for the whole kernel: 64 code units in 16 VGPRs,
-//     consumed with statically indexed v_bfe -- no memory traffic for the text in the loop;
+//     V = (V + U) | (V ^ U);  LCS = popcount(~V).  Patterns of <= 32 code units run in 32-bit
+//     words (4 full-rate VALU ops per symbol), longer ones (<= 64) in 64-bit words;
+//   * one LANE owns one right string (the "text") for the whole kernel.  Its 64 code units are kept
+//     as 32 VGPRs of two 16-bit fields holding the LDS ADDRESS of the symbol's match mask
+//     (wave's PM base + 8 * code), so one full-rate v_and / v_lshrrev per step yields the address;
 //   * the left string (the "pattern") is wave-uniform.  Each wave builds its match-mask table
-//     PM[alphabet] in LDS (one ds_write_b64 sweep to clear, ONE ds_or_b64 per wave to set: lane k
-//     ORs bit k into PM[pattern[k]]), double buffered so the next pattern's build overlaps;
-//   * PM[c] lookups are 8-byte LDS reads indexed by the lane's symbol: lanes with the same symbol
-//     broadcast, symbols c and c' only conflict when c == c' (mod 32);
-//   * both tables are sorted by length (descending): a wave stops after its longest text, and the
-//     per-row threshold test is an integer compare against lcsmin[la+lb], computed by the launcher
-//     with the reference's double arithmetic; the double score is only computed for hits.
+//     PM[alphabet] in LDS: one ds_write_b64 sweep to clear, ONE ds_or_b64 per wave to set (lane k
+//     ORs bit k into PM[pattern[k]]).  PM[c] lookups are LDS reads indexed by the lane's symbol:
+//     equal symbols broadcast, symbols c and c' only conflict when c == c' (mod 32);
+//   * both tables are sorted by length (descending): a wave stops after its longest text; the
+//     threshold test is an integer compare against lcsmin[la+lb], computed by the launcher with the
+//     reference's double arithmetic; the double score is only computed for hits;
+//   * exact prunes (NSM_FLAG_PRUNE): LCS <= min(la, lb), and LCS <= (la + lb - L1) / 2 where L1 is the
+//     L1 distance of the two strings' 32-bucket symbol histograms (8 v_sad_u8 per pair): a wave only
+//     runs the LCS for rows in which some lane can still reach its lcsmin.
 #include "nsm_common.hpp"
 
 namespace nsm {
@@ -50,14 +54,28 @@ static double indel_score_host(int la, int lb, int lcs) {
   return pct / 100.0;
 }
 
+// Load from an LDS byte address held in a register (ds_read_b32 / ds_read_b64).
+template <typename T>
+__device__ __forceinline__ T lds_load(uint32_t addr) {
+  return *reinterpret_cast<const __attribute__((address_space(3))) T*>(addr);
+}
+
+// 64-bit add in ONE VALU op (5.3 cycles; v_add_co_u32 + v_addc_co_u32 take 9.3 on gfx950).
+__device__ __forceinline__ unsigned long long add64(unsigned long long a, unsigned long long b) {
+  unsigned long long d;
+  asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+
 template <bool PRUNE>
 __global__ __launch_bounds__(kBlock) void indel_raw_kernel(
-    const uint8_t* __restrict__ lcodes, const int32_t* __restrict__ llen, const int32_t* __restrict__ lorig,
-    const uint8_t* __restrict__ rcodes, const int32_t* __restrict__ rlen, const int32_t* __restrict__ rorig,
+    const uint8_t* __restrict__ lcodes, const int32_t* __restrict__ llen, const int32_t* __restrict__ lstart,
+    const int32_t* __restrict__ lorig, const uint32_t* __restrict__ lhist, const uint8_t* __restrict__ rcodes,
+    const int32_t* __restrict__ rlen, const int32_t* __restrict__ rorig, const uint32_t* __restrict__ rhist,
     nsm_hit* __restrict__ hits, unsigned long long* __restrict__ count, const IndelRawParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_mem[];
-  // layout: [wave][buffer][pm_stride] match masks, then the lcsmin bytes
-  uint8_t* s_lcsmin = reinterpret_cast<uint8_t*>(s_mem + kWavesPerBlock * 2 * p.pm_stride);
+  // layout: [wave][pm_stride] match masks, then the lcsmin bytes
+  uint8_t* s_lcsmin = reinterpret_cast<uint8_t*>(s_mem + kWavesPerBlock * p.pm_stride);
   for (int t = threadIdx.x; t < 132; t += kBlock) s_lcsmin[t] = p.lcsmin[t];
   __syncthreads();
 
@@ -69,36 +87,47 @@ __global__ __launch_bounds__(kBlock) void indel_raw_kernel(
   const bool valid = j < p.n_right;
   const int jc = valid ? j : p.n_right - 1;
 
-  uint32_t text[16];
-  const uint4* tp = reinterpret_cast<const uint4*>(rcodes + static_cast<size_t>(jc) * 64);
+  unsigned long long* pm = s_mem + wave * p.pm_stride;
+  const uint32_t pm_base = static_cast<uint32_t>(wave * p.pm_stride * 8);  // s_mem starts at LDS offset 0
+
+  // text as LDS addresses of the symbols' masks: two 16-bit fields per VGPR.  With the prune on,
+  // LCS rows are rare (< 0.1 % of the rows a wave visits on C3), so the 32 registers are rebuilt
+  // per LCS row instead of being kept live across the histogram loop (occupancy 4 -> 8 waves/SIMD).
+  uint32_t taddr[32];
+  auto build_taddr = [&]() {
+    const uint4* tp = reinterpret_cast<const uint4*>(rcodes + static_cast<size_t>(jc) * 64);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const uint4 v = tp[q];
-    text[4 * q + 0] = v.x;
-    text[4 * q + 1] = v.y;
-    text[4 * q + 2] = v.z;
-    text[4 * q + 3] = v.w;
-  }
+    for (int q = 0; q < 4; ++q) {
+      const uint4 v = tp[q];
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t c0 = w[e] & 0xffu, c1 = (w[e] >> 8) & 0xffu, c2 = (w[e] >> 16) & 0xffu, c3 = w[e] >> 24;
+        taddr[8 * q + 2 * e + 0] = (pm_base + 8 * c0) | ((pm_base + 8 * c1) << 16);
+        taddr[8 * q + 2 * e + 1] = (pm_base + 8 * c2) | ((pm_base + 8 * c3) << 16);
+      }
+    }
+  };
+  if (!PRUNE) build_taddr();
   const int lbj = valid ? rlen[jc] : 0;
   const int jorig = rorig[jc];
-  const int nwords = (wave_first(lbj) + 3) >> 2;  // sorted descending: lane 0 has the longest text
+  const int npairs = (wave_first(lbj) + 1) >> 1;  // sorted descending: lane 0 has the longest text
+  uint32_t hr[8];
+  if (PRUNE) {
+    const uint4* hp = reinterpret_cast<const uint4*>(rhist + static_cast<size_t>(jc) * 8);
+    const uint4 h0 = hp[0], h1 = hp[1];
+    hr[0] = h0.x; hr[1] = h0.y; hr[2] = h0.z; hr[3] = h0.w;
+    hr[4] = h1.x; hr[5] = h1.y; hr[6] = h1.z; hr[7] = h1.w;
+  }
+  uint32_t lowmask = 0xffffu;  // kept in a VGPR: v_and with a VGPR operand issues at full rate
+  asm volatile("" : "+v"(lowmask));
 
-  unsigned long long* pm_base = s_mem + wave * 2 * p.pm_stride;
   const int i0 = blockIdx.y * p.rows_per_chunk;
   const int i1 = min(p.n_left, i0 + p.rows_per_chunk);
 
-  for (int i = i0; i < i1; ++i) {
-    const int la = llen[i];  // wave-uniform
-    int need;
-    if (la == 0 || lbj == 0) need = p.zero_need;
-    else need = s_lcsmin[la + lbj];
-    if (!valid) need = kNever;
-    if (PRUNE) {
-      // LCS <= min(la, lb): skip the row when no lane can reach its bound
-      if (!__any(min(la, lbj) >= need)) continue;
-    }
-    // ---- build PM for pattern i (this wave's private buffer, alternating)
-    unsigned long long* pm = pm_base + (i & 1) * p.pm_stride;
+  // ---- LCS of pattern row i (length la, match masks built here) against the lane's text
+  auto lcs_row = [&](int i, int la, bool wide) -> int {
+    if (PRUNE) build_taddr();
     for (int c = lane; c < p.pm_stride; c += kWave) pm[c] = 0ull;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -108,25 +137,101 @@ __global__ __launch_bounds__(kBlock) void indel_raw_kernel(
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-
-    // ---- Hyyro LCS over the text, one symbol per step
-    unsigned long long v = ~0ull;
+    if (!wide) {  // pattern <= 32: 32-bit words, and / add / xor / or all issue at full rate
+      uint32_t v = ~0u;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) {
-      if (w < nwords) {
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const unsigned c = (text[w] >> (8 * b)) & 0xffu;
-          const unsigned long long m = pm[c];
-          const unsigned long long u = v & m;
-          v = (v + u) | (v - u);
+      for (int w = 0; w < 32; ++w) {
+        if (w < npairs) {
+          const uint32_t m0 = lds_load<uint32_t>(taddr[w] & lowmask);
+          const uint32_t u0 = v & m0;
+          v = (v + u0) | (v ^ u0);
+          const uint32_t m1 = lds_load<uint32_t>(taddr[w] >> 16);
+          const uint32_t u1 = v & m1;
+          v = (v + u1) | (v ^ u1);
         }
       }
+      return 32 - __popc(v);
     }
-    const int lcs = 64 - __popcll(v);
-    const bool hit = lcs >= need;
-    if (__any(hit)) {
-      if (hit) emit_hit(hits, p.cap, count, indel_score(la, lbj, lcs), lorig[i], jorig);
+    unsigned long long v = ~0ull;
+#pragma unroll
+    for (int w = 0; w < 32; ++w) {
+      if (w < npairs) {
+        const unsigned long long m0 = lds_load<unsigned long long>(taddr[w] & lowmask);
+        const unsigned long long u0 = v & m0;
+        v = add64(v, u0) | (v ^ u0);
+        const unsigned long long m1 = lds_load<unsigned long long>(taddr[w] >> 16);
+        const unsigned long long u1 = v & m1;
+        v = add64(v, u1) | (v ^ u1);
+      }
+    }
+    return 64 - __popcll(v);
+  };
+
+  // rows are sorted by length (descending): rows of length 64 - c are [lstart[c], lstart[c + 1])
+  const int c_first = 64 - llen[i0];
+  const int c_last = 64 - llen[i1 - 1];
+  for (int c = c_first; c <= c_last; ++c) {
+    const int a = max(i0, lstart[c]);
+    const int b = min(i1, lstart[c + 1]);
+    if (a >= b) continue;
+    const int la = 64 - c;
+    int need;
+    if (la == 0 || lbj == 0) need = p.zero_need;
+    else need = s_lcsmin[la + lbj];
+    if (!valid) need = kNever;
+    const bool wide = la > 32;
+    if (PRUNE) {
+      // exact length filter, per class: LCS <= min(la, lb)
+      const bool fits = min(la, lbj) >= need;
+      if (!__any(fits)) continue;
+      // exact histogram filter, per row: LCS <= sum_c min(hA[c], hB[c]) = (la + lb - L1) / 2 over 32
+      // symbol buckets, i.e. the row can only hit if L1 <= la + lb - 2 * lcsmin
+      const int limit = fits ? la + lbj - 2 * need : -1;
+      auto score_row = [&](int i) {
+        const int lcs = lcs_row(i, la, wide);
+        const bool hit = lcs >= need;
+        if (__any(hit)) {
+          if (hit) emit_hit(hits, p.cap, count, indel_score(la, lbj, lcs), lorig[i], jorig);
+        }
+      };
+      // 4 rows per iteration: their 32 histogram dwords arrive with two s_load_dwordx16 issued
+      // back to back, the verdicts are shifted into a per-lane bit mask on the VALU side
+      // (v_cmp + v_addc) -- the scalar unit is shared by the CU's 4 SIMDs, keep it idle.
+      constexpr int BATCH = 4;
+      const uint32_t* __restrict__ hp = lhist + static_cast<size_t>(a) * 8;
+      int i = a;
+      for (; i + BATCH <= b; i += BATCH, hp += 8 * BATCH) {
+        uint32_t h[8 * BATCH];
+#pragma unroll
+        for (int q = 0; q < 8 * BATCH; ++q) h[q] = hp[q];
+        uint32_t cand = 0;  // bit (BATCH-1-r) = row r may reach the threshold
+#pragma unroll
+        for (int r = 0; r < BATCH; ++r) {
+          uint32_t l1 = 0;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) l1 = __builtin_amdgcn_sad_u8(h[8 * r + q], hr[q], l1);
+          asm("v_cmp_le_i32 vcc, %1, %2\n\ts_nop 1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+              : "+v"(cand) : "v"(static_cast<int>(l1)), "v"(limit) : "vcc");
+        }
+        if (__any(cand != 0)) {  // rare
+          for (int r = 0; r < BATCH; ++r)
+            if (__any((cand >> (BATCH - 1 - r)) & 1u)) score_row(i + r);
+        }
+      }
+      for (; i < b; ++i, hp += 8) {
+        uint32_t l1 = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) l1 = __builtin_amdgcn_sad_u8(hp[q], hr[q], l1);
+        if (__any(static_cast<int>(l1) <= limit)) score_row(i);
+      }
+    } else {
+      for (int i = a; i < b; ++i) {
+        const int lcs = lcs_row(i, la, wide);
+        const bool hit = lcs >= need;
+        if (__any(hit)) {
+          if (hit) emit_hit(hits, p.cap, count, indel_score(la, lbj, lcs), lorig[i], jorig);
+        }
+      }
     }
   }
 }
@@ -166,7 +271,8 @@ extern "C" int nsm_indel_raw_grid(const nsm_str_table* left, const nsm_str_table
     return NSM_E_BADARG;
   }
   if (left->n == 0 || right->n == 0) return 0;
-  if (!left->codes || !left->len || !left->orig || !right->codes || !right->len || !right->orig) {
+  if (!left->codes || !left->len || !left->orig || !left->len_start || !right->codes || !right->len ||
+      !right->orig) {
     set_error("nsm_indel_raw_grid: table has a null column");
     return NSM_E_BADARG;
   }
@@ -195,13 +301,15 @@ extern "C" int nsm_indel_raw_grid(const nsm_str_table* left, const nsm_str_table
     p.rows_per_chunk = (left->n + 65534) / 65535;
     grid.y = (left->n + p.rows_per_chunk - 1) / p.rows_per_chunk;
   }
-  const size_t lds = static_cast<size_t>(kWavesPerBlock) * 2 * p.pm_stride * 8 + 136;
+  const size_t lds = static_cast<size_t>(kWavesPerBlock) * p.pm_stride * 8 + 136;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (flags & NSM_FLAG_PRUNE)
-    hipLaunchKernelGGL((indel_raw_kernel<true>), grid, dim3(kBlock), lds, s, left->codes, left->len, left->orig,
-                       right->codes, right->len, right->orig, hits, hit_count, p);
+  const uint32_t* lh = reinterpret_cast<const uint32_t*>(left->hist);
+  const uint32_t* rh = reinterpret_cast<const uint32_t*>(right->hist);
+  if ((flags & NSM_FLAG_PRUNE) && lh && rh)
+    hipLaunchKernelGGL((indel_raw_kernel<true>), grid, dim3(kBlock), lds, s, left->codes, left->len,
+                       left->len_start, left->orig, lh, right->codes, right->len, right->orig, rh, hits, hit_count, p);
   else
-    hipLaunchKernelGGL((indel_raw_kernel<false>), grid, dim3(kBlock), lds, s, left->codes, left->len, left->orig,
-                       right->codes, right->len, right->orig, hits, hit_count, p);
+    hipLaunchKernelGGL((indel_raw_kernel<false>), grid, dim3(kBlock), lds, s, left->codes, left->len,
+                       left->len_start, left->orig, lh, right->codes, right->len, right->orig, rh, hits, hit_count, p);
   return hip_status(hipGetLastError(), "indel_raw_kernel launch");
 }

@@ -40,6 +40,8 @@ class NsmStrTable(ctypes.Structure):
         ("codes", ctypes.c_void_p),
         ("len", ctypes.c_void_p),
         ("orig", ctypes.c_void_p),
+        ("len_start", ctypes.c_void_p),
+        ("hist", ctypes.c_void_p),
         ("n", ctypes.c_int32),
         ("stride", ctypes.c_int32),
         ("alphabet", ctypes.c_int32),

@@ -281,6 +281,8 @@ class StrTable:
     stride: int
     alphabet: int
     has_empty: bool
+    hist: Optional[torch.Tensor] = None
+    len_start: Optional[torch.Tensor] = None
 
     @classmethod
     def from_codes(
@@ -303,7 +305,18 @@ class StrTable:
             raise ValueError("code unit outside the alphabet")
         perm = np.argsort(-lengths, kind="stable") if sort else np.arange(n)
         base = np.arange(n, dtype=np.int32) if orig is None else np.asarray(orig, dtype=np.int32)
+        # 32-bucket symbol histogram per row (bucket = code & 31) for the exact LCS upper bound
+        hist = np.zeros((n, 32), dtype=np.uint8)
+        if n:
+            live = np.arange(64, dtype=np.int32)[None, :] < lengths[:, None]
+            rows = np.broadcast_to(np.arange(n)[:, None], codes.shape)[live]
+            np.add.at(hist, (rows, codes[live] & 31), 1)
+        # rows of length (64 - c) occupy [len_start[c], len_start[c + 1]) in the length-sorted table
+        len_start = np.zeros(66, dtype=np.int32)
+        len_start[1:] = np.cumsum(np.bincount(lengths, minlength=65)[:65][::-1])
         return cls(
+            hist=_dev(hist[perm], device),
+            len_start=_dev(len_start, device) if sort else None,
             codes=_dev(codes[perm], device),
             len=_dev(lengths[perm], device),
             orig=_dev(base[perm], device),
@@ -333,7 +346,9 @@ class StrTable:
 
     def struct(self) -> _lib.NsmStrTable:
         return _lib.NsmStrTable(
-            self.codes.data_ptr(), self.len.data_ptr(), self.orig.data_ptr(), self.n, self.stride, self.alphabet
+            self.codes.data_ptr(), self.len.data_ptr(), self.orig.data_ptr(),
+            None if self.len_start is None else self.len_start.data_ptr(),
+            None if self.hist is None else self.hist.data_ptr(), self.n, self.stride, self.alphabet,
         )
 
     def nbytes(self) -> int:

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
     # struct layouts must match the header (sizes on LP64)
     assert ctypes.sizeof(_lib.NsmHit) == 16
     assert ctypes.sizeof(_lib.NsmSetTable) == 9 * 8 + 3 * 4 + 4
-    assert ctypes.sizeof(_lib.NsmStrTable) == 3 * 8 + 3 * 4 + 4
+    assert ctypes.sizeof(_lib.NsmStrTable) == 5 * 8 + 3 * 4 + 4
     assert ctypes.sizeof(_lib.NsmLevelItems) == 4 * 8 + 4 + 4
 
 
@@ -53,7 +53,7 @@ def test_argument_validation_without_gpu():
     cnt = ctypes.c_ulonglong(0)
     rc = lib.nsm_jaccard_raw_grid(a, b, 0.5, 0, None, 0, ctypes.addressof(cnt), None)
     assert rc == 10001 and b"width" in lib.nsm_last_error()
-    s = _lib.NsmStrTable(None, None, None, 1, 128, 10)
+    s = _lib.NsmStrTable(None, None, None, None, None, 1, 128, 10)
     rc = lib.nsm_indel_raw_grid(s, s, 0.5, 0, None, 0, ctypes.addressof(cnt), None)
     assert rc == 10002
     with pytest.raises(NotImplementedError):
@@ -111,6 +111,7 @@ def test_str_table_encoding_cpu():
     assert lt.alphabet == rt.alphabet == 3 and lt.has_empty
     assert lt.len.tolist() == [3, 2, 0] and lt.orig.tolist() == [0, 2, 1]
     assert lt.codes[0, :4].tolist() == [0, 1, 2, 3]  # pad code == alphabet size
+    assert lt.hist.shape == (3, 32) and lt.hist[0, :4].tolist() == [1, 1, 1, 0] and int(lt.hist[2].sum()) == 0
     li, ls, ri, rs = tables.encode_level_strings([["a", "ab"], ["b"]], [["c"]], "cpu")
     assert li.nlev.tolist() == [2, 1] and li.first.tolist() == [0, 2] and ls.n == 3 and rs.n == 1
 
