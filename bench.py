@@ -45,7 +45,9 @@ def parse_args():
     ap.add_argument("--workload", choices=("c2", "c3"), default="c2")
     ap.add_argument("--rows", type=int, default=0, help="override rows per side per GPU (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--capacity", type=int, default=1 << 16)
+    ap.add_argument("--capacity", type=int, default=1 << 13)
+    ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
+                    help="gloo = CPU-staged rehearsal of the N > 1 path (e.g. 2 ranks sharing one GPU)")
     return ap.parse_args()
 
 
@@ -116,7 +118,9 @@ class Workload:
             return planted
         import torch.distributed as dist
 
-        t = torch.from_numpy(planted if planted is not None else like.copy()).to(device)
+        t = torch.from_numpy(planted if planted is not None else like.copy())
+        if dist.get_backend() == "nccl":
+            t = t.to(device)
         dist.broadcast(t, src=0)
         return t.cpu().numpy()
 
@@ -137,11 +141,17 @@ def gather_hits(buf, world, device):
     import torch
     import torch.distributed as dist
 
+    if dist.get_backend() != "nccl":  # gloo rehearsal: stage through host memory
+        counts = torch.empty(world, dtype=torch.int64)
+        dist.all_gather_into_tensor(counts, buf.count.cpu())
+        out = torch.empty((world * buf.records.shape[0], 2), dtype=buf.records.dtype)
+        dist.all_gather_into_tensor(out, buf.records.cpu())
+        return out.to(device).view(world, -1, 2), counts.to(device)
     counts = torch.empty(world, dtype=torch.int64, device=device)
     dist.all_gather_into_tensor(counts, buf.count)
-    out = torch.empty((world,) + tuple(buf.records.shape), dtype=buf.records.dtype, device=device)
-    dist.all_gather_into_tensor(out, buf.records)
-    return out, counts
+    out = torch.empty((world * buf.records.shape[0], 2), dtype=buf.records.dtype, device=device)
+    dist.all_gather_into_tensor(out, buf.records)  # concatenated along dim 0
+    return out.view(world, -1, 2), counts
 
 
 def cpu_baseline(work, budget_pairs):
@@ -192,6 +202,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the match loop has no CPU fallback")
+    local_rank = local_rank % torch.cuda.device_count()  # rehearsal: several ranks may share a GPU
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -199,7 +210,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from napkon_string_matching_amd import grid
 
@@ -230,7 +244,7 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            t = torch.tensor([dt], dtype=torch.float64, device=device if args.dist_backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt

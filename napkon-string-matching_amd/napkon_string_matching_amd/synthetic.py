@@ -140,3 +140,66 @@ def cohort_records(
             }
         )
     return rows
+
+
+# ------------------------------------------------------------------ C5: cohorts at scale (vectorised)
+def c5_cohort(n: int, seed: int, vocab: int = 20_000, entries: int = 4, tokens_per_entry: int = 2,
+              n_categories: int = 32, plant_from: dict = None, plant_fraction: float = 0.01):
+    """hap / pop / suep shaped cohort of BASELINE configs[4]: every item has ``entries`` entries of
+    ``tokens_per_entry`` words ``t<id>`` (-> ``entries`` suffix-nested levels, ~8 ids) and 1-2 of
+    ``n_categories`` category labels.  Returns a dict with
+      tok    int32 [n][entries*tpe]  word ids, entry e at columns [e*tpe, (e+1)*tpe)
+      ids    int32 [n][entries*tpe]  the same words in suffix-nested order (last entry first),
+                                     de-duplicated, unique ids first, padded with -1
+      plen   uint8 [n][entries]      level l = first plen[l] ids
+      nlev   int32 [n]
+      cat    uint64[n]               category bit mask
+    """
+    rng = np.random.default_rng(seed)
+    width = entries * tokens_per_entry
+    tok = rng.integers(0, vocab, size=(n, width), dtype=np.int64).astype(np.int32)
+    if plant_from is not None:  # near-duplicate items: copy a source item, re-draw one word
+        n_plant = max(1, int(round(plant_fraction * n)))
+        targets = rng.choice(n, size=n_plant, replace=False)
+        sources = rng.integers(0, plant_from["tok"].shape[0], size=n_plant)
+        tok[targets] = plant_from["tok"][sources]
+        change = rng.random(n_plant) < 0.5
+        tok[targets[change], rng.integers(0, width, size=int(change.sum()))] = rng.integers(
+            0, vocab, size=int(change.sum()))
+        return _finish_c5(tok, rng, entries, tokens_per_entry, n_categories, vocab, targets, plant_from, sources)
+    return _finish_c5(tok, rng, entries, tokens_per_entry, n_categories, vocab, None, None, None)
+
+
+def _finish_c5(tok, rng, entries, tokens_per_entry, n_categories, vocab, targets, plant_from, sources):
+    n, width = tok.shape
+    cols = np.concatenate([np.arange(e * tokens_per_entry, (e + 1) * tokens_per_entry) for e in range(entries - 1, -1, -1)])
+    nested = tok[:, cols]
+    first = np.ones((n, width), dtype=bool)
+    for p in range(1, width):
+        first[:, p] = ~(nested[:, :p] == nested[:, p: p + 1]).any(axis=1)
+    seen = np.cumsum(first, axis=1)
+    plen = seen[:, tokens_per_entry - 1:: tokens_per_entry].astype(np.uint8)
+    order = np.argsort(~first, axis=1, kind="stable")
+    ids = np.take_along_axis(np.where(first, nested, -1), order, axis=1).astype(np.int32)
+    k = rng.integers(1, 3, size=n)
+    c1 = rng.integers(0, n_categories, size=n)
+    c2 = rng.integers(0, n_categories, size=n)
+    cat = (np.uint64(1) << c1.astype(np.uint64)) | np.where(k == 2, np.uint64(1) << c2.astype(np.uint64), np.uint64(0))
+    if targets is not None:  # planted items keep their source's categories (so the pair survives the filter)
+        cat[targets] = plant_from["cat"][sources]
+    return {"tok": tok, "ids": ids, "plen": plen, "nlev": np.full(n, entries, dtype=np.int32), "cat": cat,
+            "entries": entries, "tokens_per_entry": tokens_per_entry}
+
+
+def c5_level_token_lists(cohort: dict, rows: slice = slice(None)) -> List[List[List[str]]]:
+    """``gen_comp_value`` output of the cohort's items: per item the level token lists."""
+    tok, e, t = cohort["tok"][rows], cohort["entries"], cohort["tokens_per_entry"]
+    out = []
+    for row in tok:
+        words = [f"t{int(v)}" for v in row]
+        out.append([sorted(set(words[(e - 1 - lv) * t:]), key=str.casefold) for lv in range(e)])
+    return out
+
+
+def c5_category_lists(cohort: dict, rows: slice = slice(None)) -> List[List[str]]:
+    return [[f"cat{b}" for b in range(64) if (int(m) >> b) & 1] for m in cohort["cat"][rows]]

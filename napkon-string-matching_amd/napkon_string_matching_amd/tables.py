@@ -205,6 +205,31 @@ class SetTable:
         return cls._finish(ids, cnt, side, device, width, None, nlev=nlev, plen=plen, cat=categories, max_levels=max_levels)
 
     @classmethod
+    def from_nested_arrays(
+        cls, ids: np.ndarray, plen: np.ndarray, nlev: np.ndarray, side: str, device,
+        categories: Optional[np.ndarray] = None, width: Optional[int] = None,
+    ) -> "SetTable":
+        """Levels table from arrays that already are in suffix-nested layout: ``ids`` [n][w] unique
+        per row (negative = padding, valid ids first), ``plen`` [n][L] non-decreasing prefix lengths,
+        ``nlev`` [n] (vectorised path for large synthetic cohorts)."""
+        ids = np.asarray(ids, dtype=np.int32)
+        n, w_in = ids.shape
+        cnt = (ids >= 0).sum(axis=1).astype(np.int32)
+        width = width or pick_width(int(cnt.max()) if n else 1)
+        if w_in < width:
+            ids = np.pad(ids, ((0, 0), (0, width - w_in)), constant_values=-1)
+        elif w_in > width:
+            if n and int(cnt.max()) > width:
+                raise ValueError("row does not fit the requested width")
+            ids = ids[:, :width]
+        plen = np.asarray(plen, dtype=np.uint8)
+        max_levels = -(-plen.shape[1] // 4) * 4
+        if plen.shape[1] < max_levels:  # pad with the last value (clamped level index)
+            plen = np.concatenate([plen, np.repeat(plen[:, -1:], max_levels - plen.shape[1], axis=1)], axis=1)
+        return cls._finish(ids, cnt, side, device, width, None, nlev=np.asarray(nlev, dtype=np.int32), plen=plen,
+                           cat=categories, max_levels=max_levels)
+
+    @classmethod
     def _finish(cls, ids, cnt, side, device, width, orig, nlev=None, plen=None, cat=None, max_levels=0):
         if side not in ("left", "right"):
             raise ValueError("side must be 'left' or 'right'")

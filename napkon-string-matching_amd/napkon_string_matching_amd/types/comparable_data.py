@@ -250,6 +250,9 @@ class ComparableData:
         object addresses and so never hits; no cache file is read or written here.)"""
         del cached, cache_dir
         first = cache_threshold if cache_threshold else score_threshold
+        # the rows between `first` and `score_threshold` only ever fed the cache file: without it the
+        # result of scoring at `first` and filtering at `score_threshold` equals scoring at the max
+        first = max(first, score_threshold)
         result = self.gen_comparable(
             other,
             existing_mappings_whitelist,

@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""Levels-mode (Matcher) kernels on BASELINE configs[4]-shaped cohorts, single GPU.
+
+    python tools/bench_levels.py [--rows N] [--steps K] [--check M]
+
+Three cohorts (hap / pop / suep) of N items, 4 entries x 2 words each, 1-2 of 32 categories,
+filter_categories on, both score functions back to back, device threshold = max(cache_threshold 0.5, score_threshold 0.7)
+(reference config.yml:11-12).  Prints one JSON line; `--check M` also replays an M x M corner of
+every grid through the oracle (must be identical).
+"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+for p in (str(ROOT), str(ROOT / "napkon-string-matching_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=100_000)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--check", type=int, default=0)
+    ap.add_argument("--threshold", type=float, default=0.7)
+    ap.add_argument("--vocab", type=int, default=20_000)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    from napkon_string_matching_amd import _lib, grid, synthetic, tables
+    from napkon_string_matching_amd.compare import score_functions as sf
+
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    names = ["hap", "pop", "suep"]
+    cohorts = {}
+    for k, nm in enumerate(names):  # pop and suep carry 1 % near-duplicates of hap items
+        cohorts[nm] = synthetic.c5_cohort(args.rows, 11 + k, vocab=args.vocab, plant_from=cohorts.get("hap"))
+    pairs = [("hap", "pop"), ("hap", "suep"), ("pop", "suep")]
+
+    t0 = time.perf_counter()
+    set_tables = {}
+    for nm, c in cohorts.items():
+        for side in ("left", "right"):
+            set_tables[nm, side] = tables.SetTable.from_nested_arrays(
+                c["ids"], c["plen"], c["nlev"], side, dev, categories=c["cat"], width=16)
+    t_sets = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    level_strings = {nm: [[sf.fuzzy_operand(lv) for lv in it] for it in synthetic.c5_level_token_lists(c)]
+                     for nm, c in cohorts.items()}
+    str_tables = {}
+    for a, b in pairs:
+        str_tables[a, b] = tables.encode_level_strings(level_strings[a], level_strings[b], dev,
+                                                       cohorts[a]["cat"], cohorts[b]["cat"])
+    t_strs = time.perf_counter() - t0
+
+    buf = grid.HitBuffer(1 << 20, dev)
+    buf.scratch = torch.empty_like(buf.records)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    mode = _lib.CAT_INTERSECT_OR_BOTH_EMPTY
+
+    def run_jaccard(a, b):
+        buf.count.zero_()
+        _lib.check(lib.nsm_jaccard_levels_grid(set_tables[a, "left"].struct(), set_tables[b, "right"].struct(),
+                                               args.threshold, mode, 1, buf.records.data_ptr(), buf.capacity,
+                                               buf.count.data_ptr(), stream), "jaccard_levels")
+        lib.nsm_sort_hits(buf.records.data_ptr(), buf.scratch.data_ptr(), buf.capacity, buf.count.data_ptr(), stream)
+
+    def run_indel(a, b):
+        li, ls, ri, rs = str_tables[a, b]
+        buf.count.zero_()
+        _lib.check(lib.nsm_indel_levels_grid(li.struct(), ls.struct(), ri.struct(), rs.struct(), args.threshold,
+                                             mode, 1, buf.records.data_ptr(), buf.capacity, buf.count.data_ptr(),
+                                             stream), "indel_levels")
+        lib.nsm_sort_hits(buf.records.data_ptr(), buf.scratch.data_ptr(), buf.capacity, buf.count.data_ptr(), stream)
+
+    out = {"rows_per_cohort": args.rows, "threshold": args.threshold, "pairs_per_grid": args.rows ** 2,
+           "encode_seconds": {"sets": round(t_sets, 2), "level_strings": round(t_strs, 2)}}
+    for label, fn in (("intersection_vs_union", run_jaccard), ("fuzzy_match", run_indel)):
+        fn(*pairs[0])
+        torch.cuda.synchronize()
+        hits = []
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            for a, b in pairs:
+                fn(a, b)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        for a, b in pairs:
+            fn(a, b)
+            hits.append(int(buf.count.item()))
+        out[label] = {"ms_per_3_grids": dt * 1e3, "pairs_per_s": 3 * args.rows ** 2 / dt, "hits": hits}
+
+    if args.check:
+        from oracle import native
+
+        m = args.check
+        for a, b in pairs:
+            la = synthetic.c5_level_token_lists(cohorts[a], slice(0, m))
+            lb = synthetic.c5_level_token_lists(cohorts[b], slice(0, m))
+            vocab = {}
+            ids = lambda items: [[[vocab.setdefault(t, len(vocab)) for t in lv] for lv in it] for it in items]
+            want = native.levels(False, ids(la), ids(lb), args.threshold, cohorts[a]["cat"][:m], cohorts[b]["cat"][:m], 2)
+            sub_l = tables.SetTable.from_nested_arrays(cohorts[a]["ids"][:m], cohorts[a]["plen"][:m], cohorts[a]["nlev"][:m],
+                                                       "left", dev, categories=cohorts[a]["cat"][:m], width=16)
+            sub_r = tables.SetTable.from_nested_arrays(cohorts[b]["ids"][:m], cohorts[b]["plen"][:m], cohorts[b]["nlev"][:m],
+                                                       "right", dev, categories=cohorts[b]["cat"][:m], width=16)
+            got = grid.jaccard_levels_grid(sub_l, sub_r, args.threshold, category_mode=mode).as_tuples()
+            assert got == want, (a, b, len(got), len(want))
+            sl = [[sf.fuzzy_operand(lv) for lv in it] for it in la]
+            sr = [[sf.fuzzy_operand(lv) for lv in it] for it in lb]
+            cps = lambda items: [[[ord(ch) for ch in s] for s in it] for it in items]
+            want = native.levels(True, cps(sl), cps(sr), args.threshold, cohorts[a]["cat"][:m], cohorts[b]["cat"][:m], 2)
+            li, ls, ri, rs = tables.encode_level_strings(sl, sr, dev, cohorts[a]["cat"][:m], cohorts[b]["cat"][:m])
+            got = grid.indel_levels_grid(li, ls, ri, rs, args.threshold, category_mode=mode).as_tuples()
+            assert [(i, j) for _, i, j in got] == [(i, j) for _, i, j in want]
+            assert all(abs(x[0] - y[0]) <= 1e-6 for x, y in zip(got, want))
+        out["check"] = f"{m}x{m} corner of every grid identical to the oracle"
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
