@@ -7,19 +7,30 @@
 //   accumulated in double in that order (the weights are exact powers of two).
 //
 // Levels are suffix-nested (gen_comp_value, :283-285), so an item is ONE row of unique ids in
-// first-appearance order and level l is its first plen[l] ids.  Per pair the kernel
-//   1. finds, for every left position a, the right position pos[a] of the same id (or none) with the
-//      xor/min3 matrix of the RAW kernel: ids are stored pre-shifted, (id << 6) | position on the
-//      right and id << 6 on the left, so min_b (la ^ rb) is < 64 exactly when `a` occurs in the right
-//      row and then IS its position -- 1.5 VALU ops per id pair;
-//   2. for every step s counts the a < plenL[s] with pos[a] < plenR[s] (byte-parallel compare on
-//      the packed pos words) -- that is |A_s n B_s|; the union follows from the two prefix lengths;
-//   3. divides in double and accumulates; only lanes with at least one common id get here.
-// Lane = right item, left item wave-uniform via scalar loads, size-class dispatch as in the RAW kernel.
+// first-appearance order and level l is its first plen[l] ids.
+//
+// Structure: FILTER all pairs cheaply, VERIFY the survivors exactly -- per lane, not per wave.
+//   * lane = right item (ids in registers); the left rows of the chunk stream by, wave-uniform;
+//   * filter (per row, ~15 VALU ops): category predicate, and the necessary condition
+//         score <= |A n B| / max(|A_1|, |B_1|)  and  |A n B| <= popcount(hashbits(A) & hashbits(B)) + cA
+//     (every level from step 1 on contains level 1; signature words as in the RAW kernel).  A lane
+//     that passes appends the row to ITS OWN candidate queue in LDS;
+//   * verify: when some queue fills up (and at the end) the wave walks the queue slots; in slot k every
+//     lane gathers ITS k-th candidate row from HBM/L2 and scores the pair exactly:
+//       1. position matrix with the xor/min3 trick -- right ids are kept as (id << 6) | position, the
+//          left id as id << 6, so min_b(la ^ rb) < 64 iff `a` occurs in the right row and then IS its
+//          position;
+//       2. per step s, |A_s n B_s| = #{a < plenL[s] : pos[a] < plenR[s]} by a byte-parallel compare;
+//       3. the double quotient comes from an LDS table filled at block start with real IEEE divisions
+//          (W <= 32; W = 64 divides in place) and is accumulated with the reference's weights.
+//     A wave-wide "does ANY lane pass" test would almost always say yes for filters of this strength;
+//     lane-private queues turn a filter with pass rate p into ~p of the exact work.
 #pragma once
 #include "nsm_common.hpp"
 
 namespace nsm {
+
+constexpr int kQueueSlots = 32;  // candidate rows per lane between two verify sweeps
 
 template <int W>
 struct JacLevScalars {
@@ -32,97 +43,150 @@ struct JacLevScalars {
   int32_t emit_all;      // threshold <= 0: every pair that passes the category predicate is a hit
   double threshold;
   unsigned long long cap;
+  unsigned long long bneed;  // 16 x 4 bits: least |A n B| that can reach the threshold when
+                             // max(|A_1|, |B_1|) = m (m clamped to 15: a smaller m is a weaker, valid test)
 };
 
-// pos bytes of NL left positions against the lane's NB right ids; returns true if any matched.
-template <int W, int NL, int NB>
-__device__ __forceinline__ bool match_positions(const int32_t* __restrict__ lrow, const uint32_t (&r)[W],
-                                                uint32_t (&posw)[W / 4]) {
-  static_assert(NB >= 2 && NB % 2 == 0, "right class must be even");
-  uint32_t best = 0xffffffffu;
+template <int W>
+constexpr bool kQuotTable = (W <= 32);
+
+__device__ __forceinline__ uint32_t lev_min3u(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t d;
+  asm("v_min3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
+__device__ __forceinline__ int lev_wave_max(int v) {
 #pragma unroll
-  for (int q = 0; q < W / 4; ++q) posw[q] = 0xffffffffu;
-#pragma unroll
-  for (int a = 0; a < NL; ++a) {
-    const uint32_t la = static_cast<uint32_t>(lrow[a]) << 6;  // SALU
-    uint32_t m = min(la ^ r[0], la ^ r[1]);
-#pragma unroll
-    for (int b = 2; b < NB; b += 2) m = min(m, min(la ^ r[b], la ^ r[b + 1]));
-    best = min(best, m);
-    const uint32_t byte = min(m, 255u);
-    // replace byte (a & 3) of word a >> 2 (it holds 0xff)
-    posw[a >> 2] = (posw[a >> 2] & ~(0xffu << (8 * (a & 3)))) | (byte << (8 * (a & 3)));
-  }
-  return best < 64u;
+  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, kWave));
+  return v;
 }
 
 template <int W, int NB>
-__device__ __forceinline__ void levels_wave_rows(
+__device__ __forceinline__ void levels_wave(
     const int32_t* __restrict__ lids, const int32_t* __restrict__ lcnt, const uint64_t* __restrict__ lsig,
     const int32_t* __restrict__ lorig, const int32_t* __restrict__ lnlev, const uint8_t* __restrict__ lplen,
     const uint64_t* __restrict__ lcat, const uint8_t* __restrict__ rplen_row, nsm_hit* __restrict__ hits,
     unsigned long long* __restrict__ count, const JacLevScalars<W>& p, const uint32_t (&r)[W], uint64_t sr,
-    uint64_t catr, int lr, int jorig, bool valid, int i0, int i1) {
-  constexpr int NLS = W / 4;
-  for (int i = i0; i < i1; ++i) {
-    bool ok = valid;
-    if (p.cat_mode != NSM_CAT_NONE) ok = ok && category_match(lcat[i], catr, p.cat_mode);
-    bool want = ok;
-    if (!p.emit_all) want = ok && ((lsig[i] & sr) != 0ull);  // no common hash bit -> score 0
-    if (!__any(want)) continue;
+    uint64_t catr, int lr, int pr1, int jorig, bool valid, int i0, int i1, uint16_t* queue,
+    const double* quot, int lane) {
+  int qn = 0;  // candidates queued by this lane
+  const int bneed_r = static_cast<int>((p.bneed >> (4 * min(pr1, 15))) & 15ull);
 
-    const int nl = lcnt[i];
-    const int32_t* __restrict__ lrow = lids + static_cast<size_t>(i) * W;
-    const int cls = (nl + NLS - 1) / NLS;
-    uint32_t posw[W / 4];
-    bool any;
-    switch (cls) {
-      case 0:
+  // ---- exact score of (left row idx, this lane's right item); idx < 0: the lane idles
+  auto verify = [&](int idx) {
+    const bool active = idx >= 0;
+    const int ii = active ? idx : i0;
+    uint32_t l[W];
+    const uint4* lp = reinterpret_cast<const uint4*>(lids + static_cast<size_t>(ii) * W);
 #pragma unroll
-        for (int q = 0; q < W / 4; ++q) posw[q] = 0xffffffffu;
-        any = false;
-        break;
-      case 1: any = match_positions<W, NLS, NB>(lrow, r, posw); break;
-      case 2: any = match_positions<W, 2 * NLS, NB>(lrow, r, posw); break;
-      case 3: any = match_positions<W, 3 * NLS, NB>(lrow, r, posw); break;
-      default: any = match_positions<W, W, NB>(lrow, r, posw); break;
+    for (int q = 0; q < W / 4; ++q) {
+      const uint4 v = lp[q];
+      l[4 * q + 0] = v.x << 6;
+      l[4 * q + 1] = v.y << 6;
+      l[4 * q + 2] = v.z << 6;
+      l[4 * q + 3] = v.w << 6;
+    }
+    const int nl = lcnt[ii];
+    const int nl_max = lev_wave_max(active ? nl : 0);
+    uint32_t posw[W / 4];
+#pragma unroll
+    for (int q = 0; q < W / 4; ++q) {
+      posw[q] = 0xffffffffu;
+      if (4 * q < nl_max) {  // wave-uniform
+        uint32_t word = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t la = l[4 * q + e];
+          uint32_t m = lev_min3u(la ^ r[0], la ^ r[1], 255u);
+#pragma unroll
+          for (int b = 2; b < NB; b += 2) m = lev_min3u(m, la ^ r[b], la ^ r[b + 1]);
+          word |= m << (8 * e);  // m <= 255: the position of the match, or >= 64
+        }
+        posw[q] = word;
+      }
     }
     double score = 0.0;
-    const bool work = ok && any;
-    if (__any(work)) {
-      if (work) {
-        const int ll = lnlev[i];
-        const uint8_t* __restrict__ lpl = lplen + static_cast<size_t>(i) * p.lev_stride_l;
-        const int steps = max(ll, lr);
-        double factor = 1.0;
-        for (int s = 1; s <= steps; ++s) {
-          const int pl = lpl[min(s, p.lev_stride_l - 1)];        // = plen[min(s, Ll-1)]: rows are padded
-          const int pr = rplen_row[min(s, p.lev_stride_r - 1)];  //   with their last value
-          const uint32_t prrep = static_cast<uint32_t>(pr) * 0x01010101u;
-          int inter = 0;
+    if (active) {
+      const int ll = lnlev[ii];
+      const uint8_t* __restrict__ lpl = lplen + static_cast<size_t>(ii) * p.lev_stride_l;
+      const int steps = max(ll, lr);
+      double factor = 1.0;
+      for (int s = 1; s <= steps; ++s) {
+        const int pl = lpl[min(s, p.lev_stride_l - 1)];        // = plen[min(s, Ll-1)]: rows are padded
+        const int pr = rplen_row[min(s, p.lev_stride_r - 1)];  //   with their last value
+        const uint32_t prrep = static_cast<uint32_t>(pr) * 0x01010101u;
+        int inter = 0;
 #pragma unroll
-          for (int q = 0; q < W / 4; ++q) {
-            if (4 * q < pl) {
-              uint32_t x = posw[q];
-              const int keep = pl - 4 * q;  // bytes of this word that belong to the level
-              if (keep < 4) x |= 0xffffffffu << (8 * keep);
-              // per byte: x < pr  (x < 128 or x == 0xff; pr <= 64)
-              const uint32_t y = (x | 0x80808080u) - prrep;
-              inter += __popc(~(y | x) & 0x80808080u);
-            }
+        for (int q = 0; q < W / 4; ++q) {
+          if (4 * q < pl) {
+            uint32_t x = posw[q];
+            const int keep = pl - 4 * q;  // bytes of this word that belong to the level
+            if (keep < 4) x |= 0xffffffffu << (8 * keep);
+            // per byte: x < pr  (pr <= 64; bytes >= 128 never count)
+            const uint32_t y = (x | 0x80808080u) - prrep;
+            inter += __popc(~(y | x) & 0x80808080u);
           }
-          const int uni = pl + pr - inter;
-          const double part = uni ? static_cast<double>(inter) / static_cast<double>(uni) : 0.0;
-          factor *= 0.5;
-          score += part * factor;
+        }
+        const int uni = pl + pr - inter;
+        double part;
+        if constexpr (kQuotTable<W>) part = quot[inter * (2 * W + 1) + uni];
+        else part = uni ? static_cast<double>(inter) / static_cast<double>(uni) : 0.0;
+        factor *= 0.5;
+        score += part * factor;
+      }
+    }
+    const bool hit = active && score >= p.threshold;
+    if (__any(hit)) {
+      if (hit) emit_hit(hits, p.cap, count, score, lorig[ii], jorig);
+    }
+  };
+
+  auto flush = [&]() {
+    const int deepest = lev_wave_max(qn);
+    for (int k = 0; k < deepest; ++k) {
+      const int idx = (k < qn) ? i0 + static_cast<int>(queue[k * kWave + lane]) : -1;
+      verify(idx);
+    }
+    qn = 0;
+  };
+
+  // ---- filter: 4 left rows per iteration, their signature / category words fetched together
+  constexpr int BATCH = 4;
+  for (int i = i0; i < i1; i += BATCH) {
+    uint64_t sl[BATCH], cl[BATCH];
+    int pl1[BATCH];
+#pragma unroll
+    for (int q = 0; q < BATCH; ++q) {
+      const int ii = min(i + q, i1 - 1);
+      sl[q] = lsig[ii];
+      cl[q] = (p.cat_mode != NSM_CAT_NONE) ? lcat[ii] : 0ull;
+      pl1[q] = lplen[static_cast<size_t>(ii) * p.lev_stride_l + 1];  // = plen[min(1, L-1)] (rows are padded)
+    }
+#pragma unroll
+    for (int q = 0; q < BATCH; ++q) {
+      if (i + q < i1) {  // wave-uniform
+        bool pass = valid;
+        if (p.cat_mode != NSM_CAT_NONE) pass = pass && category_match(cl[q], catr, p.cat_mode);
+        if (!p.emit_all) {
+          const int extra_l = static_cast<int>(sl[q] >> 58);
+          const uint32_t lo = static_cast<uint32_t>(sl[q]) & static_cast<uint32_t>(sr);
+          const uint32_t hi = static_cast<uint32_t>(sl[q] >> 32) & static_cast<uint32_t>(sr >> 32);
+          int bound;
+          asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(bound) : "v"(lo), "s"(extra_l));
+          asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(bound) : "v"(hi), "v"(bound));
+          const int bneed_l = static_cast<int>((p.bneed >> (4 * min(pl1[q], 15))) & 15ull);  // SALU
+          pass = pass && bound >= max(bneed_l, bneed_r);
+        }
+        if (pass) {
+          queue[qn * kWave + lane] = static_cast<uint16_t>(i + q - i0);
+          ++qn;
         }
       }
     }
-    const bool hit = ok && (p.emit_all ? (score >= p.threshold) : (work && score >= p.threshold));
-    if (__any(hit)) {
-      if (hit) emit_hit(hits, p.cap, count, score, lorig[i], jorig);
-    }
+    if (__any(qn > kQueueSlots - BATCH)) flush();
   }
+  flush();
 }
 
 template <int W>
@@ -133,8 +197,20 @@ __global__ __launch_bounds__(kBlock) void jaccard_levels_kernel(
     const uint64_t* __restrict__ rsig, const int32_t* __restrict__ rorig, const int32_t* __restrict__ rnlev,
     const uint8_t* __restrict__ rplen, const uint64_t* __restrict__ rcat, nsm_hit* __restrict__ hits,
     unsigned long long* __restrict__ count, const JacLevScalars<W> p) {
+  __shared__ uint16_t s_queue[kWavesPerBlock][kQueueSlots * kWave];
+  __shared__ double s_quot[kQuotTable<W> ? (W + 1) * (2 * W + 1) : 1];
+  if constexpr (kQuotTable<W>) {
+    // k / u by real IEEE double division, exactly what the reference's Python `/` computes; 0/0
+    // (an empty-vs-empty level the host has already cleared or blacklisted) is defined as 0
+    for (int t = threadIdx.x; t < (W + 1) * (2 * W + 1); t += kBlock) {
+      const int k = t / (2 * W + 1), u = t % (2 * W + 1);
+      s_quot[t] = u ? static_cast<double>(k) / static_cast<double>(u) : 0.0;
+    }
+    __syncthreads();
+  }
   const int lane = threadIdx.x & (kWave - 1);
-  const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int wave = threadIdx.x >> 6;
+  const int tile = blockIdx.x * kWavesPerBlock + wave;
   if (tile * kWave >= p.n_right) return;
   const int j = tile * kWave + lane;
   const bool valid = j < p.n_right;
@@ -156,6 +232,7 @@ __global__ __launch_bounds__(kBlock) void jaccard_levels_kernel(
   const int lr = rnlev[jc];
   const int jorig = rorig[jc];
   const uint8_t* rplen_row = rplen + static_cast<size_t>(jc) * p.lev_stride_r;
+  const int pr1 = rplen_row[1];
   const int nbmax = wave_first(nrj);
 
   const int i0 = blockIdx.y * p.rows_per_chunk;
@@ -163,9 +240,9 @@ __global__ __launch_bounds__(kBlock) void jaccard_levels_kernel(
 
   constexpr int NBS = W / 8;
   const int cls = (nbmax + NBS - 1) / NBS;
-#define NSM_LEV_CASE(K)                                                                                \
-  levels_wave_rows<W, (K) * NBS>(lids, lcnt, lsig, lorig, lnlev, lplen, lcat, rplen_row, hits, count, p, r, \
-                                 sr, catr, lr, jorig, valid, i0, i1)
+#define NSM_LEV_CASE(K)                                                                               \
+  levels_wave<W, (K) * NBS>(lids, lcnt, lsig, lorig, lnlev, lplen, lcat, rplen_row, hits, count, p, r, sr, \
+                            catr, lr, pr1, jorig, valid, i0, i1, s_queue[wave], s_quot, lane)
   switch (cls) {
     case 0:
     case 1: NSM_LEV_CASE(1); break;
@@ -181,11 +258,13 @@ __global__ __launch_bounds__(kBlock) void jaccard_levels_kernel(
 }
 
 inline int lev_rows_per_chunk(int n_left, int n_tiles) {
-  const long long want_waves = 16ll * 256 * 32;
+  // big chunks: the per-lane queues fill more evenly and the final flush is amortised; 4096 rows
+  // keeps a row offset inside the queue's 16 bits
+  const long long want_waves = 4ll * 256 * 32;
   long long chunks = (want_waves + n_tiles - 1) / (n_tiles > 0 ? n_tiles : 1);
   if (chunks < 1) chunks = 1;
   long long rows = (n_left + chunks - 1) / chunks;
-  if (rows < 128) rows = 128;
+  if (rows < 512) rows = 512;
   if (rows > 4096) rows = 4096;
   return static_cast<int>(rows);
 }
@@ -194,19 +273,28 @@ template <int W>
 int launch_levels(const nsm_set_table* l, const nsm_set_table* r, double threshold, int32_t category_mode,
                   uint32_t flags, nsm_hit* hits, uint64_t capacity, unsigned long long* hit_count,
                   hipStream_t stream) {
-  (void)flags;  // the signature test is exact and always on (it is disabled by emit_all)
+  (void)flags;  // the filter is exact and always on (emit_all turns its score bound off)
   JacLevScalars<W> p;
   p.n_left = l->n; p.n_right = r->n; p.cap = capacity;
   p.lev_stride_l = l->max_levels; p.lev_stride_r = r->max_levels;
   p.cat_mode = category_mode;
   p.threshold = threshold;
   p.emit_all = !(threshold > 0.0);  // also true for NaN: then nothing compares >= and nothing is emitted
+  // score < |A n B| / m with m = max(|A_1|, |B_1|) (every level from step 1 on contains level 1 and
+  // the weights sum to less than 1): a pair needs |A n B| >= threshold * m.  The factor (1 - 1e-9)
+  // keeps the test necessary under the rounding of the double accumulation.
+  p.bneed = 0;
+  for (int m = 0; m < 16; ++m) {
+    int need = 0;
+    while (need < 15 && static_cast<double>(need) < threshold * static_cast<double>(m) * (1.0 - 1e-9)) ++need;
+    p.bneed |= static_cast<unsigned long long>(need) << (4 * m);
+  }
   const int n_tiles = (r->n + kWave - 1) / kWave;
   p.rows_per_chunk = lev_rows_per_chunk(l->n, n_tiles);
   dim3 grid((n_tiles + kWavesPerBlock - 1) / kWavesPerBlock, (l->n + p.rows_per_chunk - 1) / p.rows_per_chunk);
   if (grid.y > 65535) {
-    p.rows_per_chunk = (l->n + 65534) / 65535;
-    grid.y = (l->n + p.rows_per_chunk - 1) / p.rows_per_chunk;
+    set_error("nsm_jaccard_levels_grid: more than 65535 * 4096 left rows");
+    return NSM_E_UNSUPPORTED;
   }
   hipLaunchKernelGGL((jaccard_levels_kernel<W>), grid, dim3(kBlock), 0, stream, l->ids, l->cnt, l->sig, l->orig,
                      l->nlev, l->plen, l->cat, r->ids, r->cnt, r->sig, r->orig, r->nlev, r->plen, r->cat, hits,
