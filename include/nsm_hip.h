@@ -103,14 +103,23 @@ typedef struct nsm_str_table {
 /* Items whose levels are rows of a nsm_str_table (levels mode of fuzzy_match).
  *   first  device int32 [n]  row of level 0 in the string table; level l is row first+l
  *   nlev   device int32 [n]
- *   orig   device int32 [n]
- *   cat    device uint64[n] or NULL
+ *   orig   device int32 [n]  caller's item id (an item may appear in several rows, see seg)
+ *   cat    device uint64[n] or NULL: the item's full category mask
+ *   -- category partition (both NULL, or both set on BOTH sides) --
+ *   seg        device int32 [n]   the ONE category (bit index) this row stands for: an item with k
+ *                                 categories has k rows; rows are sorted by seg
+ *   seg_start  device int32 [65]  rows of category c are [seg_start[c], seg_start[c+1])
+ *   With a partition the grid only visits (left row, right row) pairs of the same category and
+ *   reports a pair in its LOWEST common category only, i.e. exactly the pairs with
+ *   (cat_left & cat_right) != 0, each once.
  */
 typedef struct nsm_level_items {
   const int32_t* first;
   const int32_t* nlev;
   const int32_t* orig;
   const uint64_t* cat;
+  const int32_t* seg;
+  const int32_t* seg_start;
   int32_t n;
 } nsm_level_items;
 

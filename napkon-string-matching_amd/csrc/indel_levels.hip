@@ -39,12 +39,29 @@ __device__ __forceinline__ int wave_max(int v) {
   return v;
 }
 
+__device__ __forceinline__ unsigned long long lev_add64(unsigned long long a, unsigned long long b) {
+  unsigned long long d;  // one VALU op (see indel_raw.hip)
+  asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+
+__device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
+  uint32_t lo = static_cast<uint32_t>(v), hi = static_cast<uint32_t>(v >> 32);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo |= __shfl_xor(lo, off, kWave);
+    hi |= __shfl_xor(hi, off, kWave);
+  }
+  return (static_cast<unsigned long long>(hi) << 32) | lo;
+}
+
 __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
     const int32_t* __restrict__ lfirst, const int32_t* __restrict__ lnlev, const int32_t* __restrict__ lorig,
-    const uint64_t* __restrict__ lcat, const uint8_t* __restrict__ lcodes, const int32_t* __restrict__ llen,
-    const int32_t* __restrict__ rfirst, const int32_t* __restrict__ rnlev, const int32_t* __restrict__ rorig,
-    const uint64_t* __restrict__ rcat, const uint8_t* __restrict__ rcodes, const int32_t* __restrict__ rlen,
-    nsm_hit* __restrict__ hits, unsigned long long* __restrict__ count, const IndelLevParams p) {
+    const uint64_t* __restrict__ lcat, const int32_t* __restrict__ lsegstart, const uint8_t* __restrict__ lcodes,
+    const int32_t* __restrict__ llen, const int32_t* __restrict__ rfirst, const int32_t* __restrict__ rnlev,
+    const int32_t* __restrict__ rorig, const uint64_t* __restrict__ rcat, const int32_t* __restrict__ rseg,
+    const uint8_t* __restrict__ rcodes, const int32_t* __restrict__ rlen, nsm_hit* __restrict__ hits,
+    unsigned long long* __restrict__ count, const IndelLevParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_pm[];  // [wave][pm_stride]
 
   const int lane = threadIdx.x & (kWave - 1);
@@ -60,6 +77,8 @@ __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
   const int jorig = rorig[jc];
   const uint64_t catr = (p.cat_mode != NSM_CAT_NONE) ? rcat[jc] : 0ull;
   const int lr_max = wave_max(valid ? lr : 0);
+  const bool partitioned = rseg != nullptr;
+  const int myseg = partitioned ? rseg[jc] : 0;
 
   unsigned long long* pm = s_pm + wave * p.pm_stride;
   const int i0 = blockIdx.y * p.rows_per_chunk;
@@ -69,10 +88,8 @@ __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
   int text_row = -1;
   int lb = 0;
 
-  for (int i = i0; i < i1; ++i) {
-    bool ok = valid;
-    if (p.cat_mode != NSM_CAT_NONE) ok = ok && category_match(lcat[i], catr, p.cat_mode);
-    if (!__any(ok)) continue;
+  // ---- all steps of left row i against the lanes flagged `ok`
+  auto score_row = [&](int i, bool ok) {
     const int ll = lnlev[i];
     const int lrow0 = lfirst[i];
     const int steps_w = max(ll, lr_max);
@@ -83,7 +100,7 @@ __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
     int la = 0;
     for (int s = 1; s <= steps_w; ++s) {
       const bool active = ok && s <= steps_l;
-      // ---- left level (wave-uniform): rebuild the match masks when the level changes
+      // left level (wave-uniform): rebuild the match masks when the level changes
       const int lrow = lrow0 + max(0, min(s, ll - 1));
       if (lrow != pm_row) {
         pm_row = lrow;
@@ -98,7 +115,7 @@ __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
-      // ---- right level (per lane): reload the row only when its index changes
+      // right level (per lane): reload the row only when its index changes
       const int rrow = rrow0 + max(0, min(s, lr - 1));
       if (rrow != text_row) {
         text_row = rrow;
@@ -123,7 +140,7 @@ __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
             const unsigned c = (text[w] >> (8 * b)) & 0xffu;
             const unsigned long long m = pm[c];
             const unsigned long long u = v & m;
-            v = (v + u) | (v - u);
+            v = lev_add64(v, u) | (v ^ u);
           }
         }
       }
@@ -134,6 +151,29 @@ __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
     const bool hit = ok && score >= p.threshold;
     if (__any(hit)) {
       if (hit) emit_hit(hits, p.cap, count, score, lorig[i], jorig);
+    }
+  };
+
+  if (partitioned) {
+    // both sides are grouped by category: visit the left rows of the categories this wave's lanes
+    // stand for, and report a pair in its lowest common category only
+    unsigned long long cats = wave_or64(valid ? (1ull << myseg) : 0ull);
+    while (cats) {
+      const int c = __builtin_ctzll(cats);
+      cats &= cats - 1;
+      const int a = max(i0, lsegstart[c]);
+      const int b = min(i1, lsegstart[c + 1]);
+      const unsigned long long lower = (1ull << c) - 1ull;
+      for (int i = a; i < b; ++i) {
+        const bool ok = valid && myseg == c && ((lcat[i] & catr & lower) == 0ull);
+        if (__any(ok)) score_row(i, ok);
+      }
+    }
+  } else {
+    for (int i = i0; i < i1; ++i) {
+      bool ok = valid;
+      if (p.cat_mode != NSM_CAT_NONE) ok = ok && category_match(lcat[i], catr, p.cat_mode);
+      if (__any(ok)) score_row(i, ok);
     }
   }
 }
@@ -170,6 +210,12 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
     return NSM_E_BADARG;
   }
   if (left->n == 0 || right->n == 0) return 0;
+  if ((left->seg == nullptr) != (right->seg == nullptr) || (left->seg && (!left->seg_start || !left->cat ||
+      !right->cat || category_mode != NSM_CAT_INTERSECT))) {
+    set_error("nsm_indel_levels_grid: a category partition needs seg/seg_start/cat on both sides and "
+              "NSM_CAT_INTERSECT");
+    return NSM_E_BADARG;
+  }
   if (!left->first || !left->nlev || !left->orig || !right->first || !right->nlev || !right->orig ||
       !left_strings->codes || !left_strings->len || !right_strings->codes || !right_strings->len ||
       (category_mode != NSM_CAT_NONE && (!left->cat || !right->cat))) {
@@ -195,8 +241,8 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
   }
   const size_t lds = static_cast<size_t>(kWavesPerBlock) * p.pm_stride * 8;
   hipLaunchKernelGGL(indel_levels_kernel, grid, dim3(kBlock), lds, static_cast<hipStream_t>(stream), left->first,
-                     left->nlev, left->orig, left->cat, left_strings->codes, left_strings->len, right->first,
-                     right->nlev, right->orig, right->cat, right_strings->codes, right_strings->len, hits, hit_count,
-                     p);
+                     left->nlev, left->orig, left->cat, left->seg_start, left_strings->codes, left_strings->len,
+                     right->first, right->nlev, right->orig, right->cat, right->seg, right_strings->codes,
+                     right_strings->len, hits, hit_count, p);
   return hip_status(hipGetLastError(), "indel_levels_kernel launch");
 }

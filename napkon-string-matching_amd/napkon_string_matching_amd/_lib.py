@@ -54,6 +54,8 @@ class NsmLevelItems(ctypes.Structure):
         ("nlev", ctypes.c_void_p),
         ("orig", ctypes.c_void_p),
         ("cat", ctypes.c_void_p),
+        ("seg", ctypes.c_void_p),
+        ("seg_start", ctypes.c_void_p),
         ("n", ctypes.c_int32),
     ]
 

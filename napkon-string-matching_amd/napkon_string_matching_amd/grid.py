@@ -162,6 +162,8 @@ def indel_levels_grid(
     lib = _lib.load()
     li, ls, ri, rs = left.struct(), left_strings.struct(), right.struct(), right_strings.struct()
     flags = _lib.FLAG_PRUNE if prune else 0
+    if left.category_mode is not None:  # the encoder may have rewritten the predicate (partition)
+        category_mode = left.category_mode
 
     def launch(buf: HitBuffer, stream: int) -> int:
         return lib.nsm_indel_levels_grid(

@@ -402,25 +402,58 @@ class LevelItems:
     orig: torch.Tensor
     cat: Optional[torch.Tensor]
     n: int
+    seg: Optional[torch.Tensor] = None
+    seg_start: Optional[torch.Tensor] = None
+    category_mode: Optional[int] = None  # the mode the kernel must be called with (set by the encoder)
 
     def struct(self) -> _lib.NsmLevelItems:
+        def ptr(t):
+            return None if t is None else t.data_ptr()
+
         return _lib.NsmLevelItems(
-            self.first.data_ptr(), self.nlev.data_ptr(), self.orig.data_ptr(),
-            None if self.cat is None else self.cat.data_ptr(), self.n,
+            self.first.data_ptr(), self.nlev.data_ptr(), self.orig.data_ptr(), ptr(self.cat), ptr(self.seg),
+            ptr(self.seg_start), self.n,
         )
+
+
+EMPTY_CATEGORY_BIT = 63  # stands for "no category at all" when empty-vs-empty counts as a match
 
 
 def encode_level_strings(
     left_items: Sequence[Sequence[str]], right_items: Sequence[Sequence[str]], device,
     left_cat: Optional[np.ndarray] = None, right_cat: Optional[np.ndarray] = None,
+    category_mode: int = _lib.CAT_NONE, partition: bool = True,
 ):
-    """Levels-mode fuzzy operands: every level of every item is one (pre-processed) string."""
+    """Levels-mode fuzzy operands: every level of every item is one (pre-processed) string.
+
+    With a category predicate (and ``partition``) both sides are PARTITIONED by category: an item
+    with k categories becomes k rows, rows are grouped per category, and the kernel only visits
+    same-category pairs (each matching pair once, in its lowest common category).  That turns the
+    predicate from a per-lane mask test -- which saves nothing, a wavefront of 64 unrelated items
+    almost always contains one that matches -- into not visiting the other ~(1 - k/C) of the grid.
+    """
     alpha = Alphabet()
     for items in (left_items, right_items):
         for levels in items:
             for s in levels:
                 for ch in s:
                     alpha.code(ch)
+
+    use_cat = category_mode != _lib.CAT_NONE and left_cat is not None and right_cat is not None
+    mode = category_mode if use_cat else _lib.CAT_NONE
+    cats = {}
+    if use_cat:
+        for name, cat in (("l", left_cat), ("r", right_cat)):
+            cats[name] = np.asarray(cat, dtype=np.uint64).copy()
+        if partition:
+            if mode == _lib.CAT_INTERSECT_OR_BOTH_EMPTY:
+                if any(int(c.max(initial=0)) >> EMPTY_CATEGORY_BIT for c in cats.values()):
+                    partition = False  # all 64 bits are real categories: keep the per-lane predicate
+                else:  # "both empty" becomes one more category shared by the empty items
+                    for c in cats.values():
+                        c[c == 0] = np.uint64(1) << np.uint64(EMPTY_CATEGORY_BIT)
+                    mode = _lib.CAT_INTERSECT
+    do_partition = use_cat and partition
 
     def side(items, cat):
         flat: List[str] = []
@@ -433,15 +466,31 @@ def encode_level_strings(
             nlev[k] = len(levels)
             flat.extend(levels)
         table = StrTable.from_strings(flat, alpha, device, sort=False)
-        # items sorted by level count (descending) so that a wavefront's items have similar depth
-        perm = np.argsort(-nlev, kind="stable")
+        item = np.arange(len(items), dtype=np.int32)
+        seg = seg_start = None
+        if do_partition:
+            rows, segs = [], []
+            for c in range(64):
+                has = np.flatnonzero((cat >> np.uint64(c)) & np.uint64(1))
+                rows.append(has.astype(np.int32))
+                segs.append(np.full(len(has), c, dtype=np.int32))
+            item = np.concatenate(rows) if rows else item[:0]
+            seg = np.concatenate(segs) if segs else np.zeros(0, np.int32)
+            # inside a category: deeper items first, so a wavefront's items have similar depth
+            order = np.lexsort((-nlev[item], seg))
+            item, seg = item[order], seg[order]
+            seg_start = np.zeros(65, dtype=np.int32)
+            seg_start[1:] = np.cumsum(np.bincount(seg, minlength=64)[:64])
+        else:
+            item = item[np.argsort(-nlev, kind="stable")]
         li = LevelItems(
-            first=_dev(first[perm], device), nlev=_dev(nlev[perm], device),
-            orig=_dev(np.arange(len(items), dtype=np.int32)[perm], device),
-            cat=None if cat is None else _dev(np.asarray(cat, dtype=np.uint64)[perm], device), n=len(items),
+            first=_dev(first[item], device), nlev=_dev(nlev[item], device), orig=_dev(item.astype(np.int32), device),
+            cat=None if cat is None else _dev(cat[item], device), n=len(item),
+            seg=None if seg is None else _dev(seg, device),
+            seg_start=None if seg_start is None else _dev(seg_start, device), category_mode=mode,
         )
         return li, table
 
-    l_items, l_table = side(left_items, left_cat)
-    r_items, r_table = side(right_items, right_cat)
+    l_items, l_table = side(left_items, cats.get("l"))
+    r_items, r_table = side(right_items, cats.get("r"))
     return l_items, l_table, r_items, r_table

@@ -513,5 +513,5 @@ def _levels_grid(plugin, levels_l, levels_r, threshold, cat_l, cat_r, cat_mode=_
             raise NotImplementedError("vocabulary of 2^25 or more distinct tokens")
         return grid.jaccard_levels_grid(lt, rt, threshold, category_mode=cat_mode)
     prep = lambda items: [[score_functions.fuzzy_operand(lv) for lv in it] for it in items]
-    li, ls, ri, rs = tables.encode_level_strings(prep(levels_l), prep(levels_r), dev, cat_l, cat_r)
+    li, ls, ri, rs = tables.encode_level_strings(prep(levels_l), prep(levels_r), dev, cat_l, cat_r, cat_mode)
     return grid.indel_levels_grid(li, ls, ri, rs, threshold, category_mode=cat_mode)

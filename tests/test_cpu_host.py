@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol():
     assert ctypes.sizeof(_lib.NsmHit) == 16
     assert ctypes.sizeof(_lib.NsmSetTable) == 9 * 8 + 3 * 4 + 4
     assert ctypes.sizeof(_lib.NsmStrTable) == 5 * 8 + 3 * 4 + 4
-    assert ctypes.sizeof(_lib.NsmLevelItems) == 4 * 8 + 4 + 4
+    assert ctypes.sizeof(_lib.NsmLevelItems) == 6 * 8 + 4 + 4
 
 
 def test_argument_validation_without_gpu():

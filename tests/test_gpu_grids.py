@@ -215,10 +215,12 @@ def test_indel_levels_random(dev, max_levels):
     left, right = [item() for _ in range(90)], [item() for _ in range(140)]
     lcat = np.array([rng.choice([0, 1, 2, 3]) for _ in left], dtype=np.uint64)
     rcat = np.array([rng.choice([0, 1, 2]) for _ in right], dtype=np.uint64)
-    li, ls, ri, rs = tables.encode_level_strings(left, right, dev, lcat, rcat)
     cps = lambda items: [[[ord(c) for c in s] for s in it] for it in items]
-    for thr in (0.0, 0.25, 0.5):
-        for mode in (_lib.CAT_NONE, _lib.CAT_INTERSECT_OR_BOTH_EMPTY):
+    for mode, partition in ((_lib.CAT_NONE, True), (_lib.CAT_INTERSECT_OR_BOTH_EMPTY, True), (_lib.CAT_INTERSECT, True),
+                            (_lib.CAT_INTERSECT_OR_BOTH_EMPTY, False)):
+        li, ls, ri, rs = tables.encode_level_strings(left, right, dev, lcat, rcat, mode, partition=partition)
+        assert (li.seg is not None) == (partition and mode != _lib.CAT_NONE)
+        for thr in (0.0, 0.25, 0.5):
             want = native.levels(True, cps(left), cps(right), thr, lcat, rcat, mode, cap=1 << 16)
             got = grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, capacity=1 << 11)
             _same_hits(got, want, FUZZY_TOL)

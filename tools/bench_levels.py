@@ -56,7 +56,8 @@ def main():
     str_tables = {}
     for a, b in pairs:
         str_tables[a, b] = tables.encode_level_strings(level_strings[a], level_strings[b], dev,
-                                                       cohorts[a]["cat"], cohorts[b]["cat"])
+                                                       cohorts[a]["cat"], cohorts[b]["cat"],
+                                                       _lib.CAT_INTERSECT_OR_BOTH_EMPTY)
     t_strs = time.perf_counter() - t0
 
     buf = grid.HitBuffer(1 << 20, dev)
@@ -75,7 +76,7 @@ def main():
         li, ls, ri, rs = str_tables[a, b]
         buf.count.zero_()
         _lib.check(lib.nsm_indel_levels_grid(li.struct(), ls.struct(), ri.struct(), rs.struct(), args.threshold,
-                                             mode, 1, buf.records.data_ptr(), buf.capacity, buf.count.data_ptr(),
+                                             li.category_mode, 1, buf.records.data_ptr(), buf.capacity, buf.count.data_ptr(),
                                              stream), "indel_levels")
         lib.nsm_sort_hits(buf.records.data_ptr(), buf.scratch.data_ptr(), buf.capacity, buf.count.data_ptr(), stream)
 
@@ -116,7 +117,7 @@ def main():
             sr = [[sf.fuzzy_operand(lv) for lv in it] for it in lb]
             cps = lambda items: [[[ord(ch) for ch in s] for s in it] for it in items]
             want = native.levels(True, cps(sl), cps(sr), args.threshold, cohorts[a]["cat"][:m], cohorts[b]["cat"][:m], 2)
-            li, ls, ri, rs = tables.encode_level_strings(sl, sr, dev, cohorts[a]["cat"][:m], cohorts[b]["cat"][:m])
+            li, ls, ri, rs = tables.encode_level_strings(sl, sr, dev, cohorts[a]["cat"][:m], cohorts[b]["cat"][:m], mode)
             got = grid.indel_levels_grid(li, ls, ri, rs, args.threshold, category_mode=mode).as_tuples()
             assert [(i, j) for _, i, j in got] == [(i, j) for _, i, j in want]
             assert all(abs(x[0] - y[0]) <= 1e-6 for x, y in zip(got, want))
