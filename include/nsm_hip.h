@@ -64,6 +64,8 @@ typedef struct nsm_hit {
  *   nlev  device int32 [n]         number of levels L (>= 1)
  *   plen  device uint8 [n][max_levels]  level l = the first plen[l] ids of the row (non-decreasing)
  *   cat   device uint64[n]         category bit mask, NULL when categories are not filtered
+ *   filt  device uint32[n][8]      filter record of the row: {sig lo, sig hi, cat lo, cat hi,
+ *                                  plen[min(1,L-1)] | cnt << 8 | nlev << 16, 0, 0, 0} (one s_load per 2 rows)
  */
 typedef struct nsm_set_table {
   const int32_t* ids;
@@ -75,6 +77,7 @@ typedef struct nsm_set_table {
   const int32_t* nlev;
   const uint8_t* plen;
   const uint64_t* cat;
+  const uint32_t* filt;
   int32_t n;
   int32_t width;      /* 16, 32 or 64 */
   int32_t max_levels; /* row stride of plen */

@@ -39,7 +39,7 @@ extern "C" int nsm_jaccard_levels_grid(const nsm_set_table* left, const nsm_set_
   if (left->n == 0 || right->n == 0) return 0;
   const nsm_set_table* t[2] = {left, right};
   for (int k = 0; k < 2; ++k) {
-    if (!t[k]->ids || !t[k]->cnt || !t[k]->sig || !t[k]->orig || !t[k]->nlev || !t[k]->plen ||
+    if (!t[k]->ids || !t[k]->cnt || !t[k]->sig || !t[k]->orig || !t[k]->nlev || !t[k]->plen || !t[k]->filt ||
         (category_mode != NSM_CAT_NONE && !t[k]->cat)) {
       set_error("nsm_jaccard_levels_grid: %s table has a null column", k ? "right" : "left");
       return NSM_E_BADARG;

@@ -11,8 +11,8 @@
 //
 // Structure: FILTER all pairs cheaply, VERIFY the survivors exactly -- per lane, not per wave.
 //   * lane = right item (ids in registers); the left rows of the chunk stream by, wave-uniform;
-//   * filter (per row, ~15 VALU ops): category predicate, and the necessary condition
-//         score <= |A n B| / max(|A_1|, |B_1|)  and  |A n B| <= popcount(hashbits(A) & hashbits(B)) + cA
+//   * filter (per row, ~13 VALU ops): category predicate, and the necessary condition
+//         score <= |A n B| / |B_1|  and  |A n B| <= popcount(hashbits(A) & hashbits(B)) + cA
 //     (every level from step 1 on contains level 1; signature words as in the RAW kernel).  A lane
 //     that passes appends the row to ITS OWN candidate queue in LDS;
 //   * verify: when some queue fills up (and at the end) the wave walks the queue slots; in slot k every
@@ -69,7 +69,7 @@ __device__ __forceinline__ void levels_wave(
     const uint64_t* __restrict__ lcat, const uint8_t* __restrict__ rplen_row, nsm_hit* __restrict__ hits,
     unsigned long long* __restrict__ count, const JacLevScalars<W>& p, const uint32_t (&r)[W], uint64_t sr,
     uint64_t catr, int lr, int pr1, int jorig, bool valid, int i0, int i1, uint16_t* queue,
-    const double* quot, int lane) {
+    const double* quot, const uint32_t* __restrict__ lfilt, int lane) {
   int qn = 0;  // candidates queued by this lane
   const int bneed_r = static_cast<int>((p.bneed >> (4 * min(pr1, 15))) & 15ull);
 
@@ -151,40 +151,51 @@ __device__ __forceinline__ void levels_wave(
     qn = 0;
   };
 
-  // ---- filter: 4 left rows per iteration, their signature / category words fetched together
+  // ---- filter: 4 left rows per iteration.  A row's filter record is 8 dwords (signature word,
+  // category mask, sizes) so that 4 rows arrive with two s_load_dwordx16; the verdict is pushed
+  // into the lane's queue without branches: every lane stores the row offset at its current queue
+  // tail, only passing lanes advance the tail (v_addc).  Everything wave-uniform here costs scalar-
+  // unit cycles, which the CU's 4 SIMDs share -- hence one pointer increment per batch, no per-row
+  // address arithmetic, no exec-mask juggling.
   constexpr int BATCH = 4;
-  for (int i = i0; i < i1; i += BATCH) {
-    uint64_t sl[BATCH], cl[BATCH];
-    int pl1[BATCH];
-#pragma unroll
-    for (int q = 0; q < BATCH; ++q) {
-      const int ii = min(i + q, i1 - 1);
-      sl[q] = lsig[ii];
-      cl[q] = (p.cat_mode != NSM_CAT_NONE) ? lcat[ii] : 0ull;
-      pl1[q] = lplen[static_cast<size_t>(ii) * p.lev_stride_l + 1];  // = plen[min(1, L-1)] (rows are padded)
+  const bool use_cat = p.cat_mode != NSM_CAT_NONE;
+  const bool both_empty = p.cat_mode == NSM_CAT_INTERSECT_OR_BOTH_EMPTY;
+  const int need_r = valid ? (p.emit_all ? -1 : bneed_r) : 1 << 20;  // invalid lanes never pass
+  const uint32_t catr_lo = static_cast<uint32_t>(catr), catr_hi = static_cast<uint32_t>(catr >> 32);
+  const uint32_t sr_lo = static_cast<uint32_t>(sr), sr_hi = static_cast<uint32_t>(sr >> 32);
+  uint32_t rowv = 0;                                  // row offset inside the chunk, in a VGPR
+  const uint32_t qbase = static_cast<uint32_t>(lane * 2);  // byte offset of the lane's queue column
+
+  auto filter_row = [&](uint32_t sig_lo, uint32_t sig_hi, uint32_t cat_lo, uint32_t cat_hi) {
+    int bound;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(bound) : "v"(sig_lo & sr_lo), "s"(sig_hi >> 26));
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(bound) : "v"(sig_hi & sr_hi), "v"(bound));
+    bool pass = bound >= need_r;
+    if (use_cat) {
+      const uint32_t common = (cat_lo & catr_lo) | (cat_hi & catr_hi);
+      bool cat_ok = common != 0u;
+      if (both_empty) cat_ok = cat_ok || ((cat_lo | cat_hi | catr_lo | catr_hi) == 0u);
+      pass = pass && cat_ok;
     }
+    // branch-free append
+    queue[(static_cast<uint32_t>(qn) * (kWave * 2) + qbase) >> 1] = static_cast<uint16_t>(rowv);
+    qn += pass ? 1 : 0;
+    rowv += 1;
+  };
+
+  const uint32_t* __restrict__ fp = lfilt + static_cast<size_t>(i0) * 8;
+  int i = i0;
+  for (; i + BATCH <= i1; i += BATCH, fp += 8 * BATCH) {
+    uint32_t f[8 * BATCH];
 #pragma unroll
-    for (int q = 0; q < BATCH; ++q) {
-      if (i + q < i1) {  // wave-uniform
-        bool pass = valid;
-        if (p.cat_mode != NSM_CAT_NONE) pass = pass && category_match(cl[q], catr, p.cat_mode);
-        if (!p.emit_all) {
-          const int extra_l = static_cast<int>(sl[q] >> 58);
-          const uint32_t lo = static_cast<uint32_t>(sl[q]) & static_cast<uint32_t>(sr);
-          const uint32_t hi = static_cast<uint32_t>(sl[q] >> 32) & static_cast<uint32_t>(sr >> 32);
-          int bound;
-          asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(bound) : "v"(lo), "s"(extra_l));
-          asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(bound) : "v"(hi), "v"(bound));
-          const int bneed_l = static_cast<int>((p.bneed >> (4 * min(pl1[q], 15))) & 15ull);  // SALU
-          pass = pass && bound >= max(bneed_l, bneed_r);
-        }
-        if (pass) {
-          queue[qn * kWave + lane] = static_cast<uint16_t>(i + q - i0);
-          ++qn;
-        }
-      }
-    }
-    if (__any(qn > kQueueSlots - BATCH)) flush();
+    for (int q = 0; q < 8 * BATCH; ++q) f[q] = fp[q];
+#pragma unroll
+    for (int q = 0; q < BATCH; ++q) filter_row(f[8 * q + 0], f[8 * q + 1], f[8 * q + 2], f[8 * q + 3]);
+    if (__any(qn > kQueueSlots - BATCH - 1)) flush();
+  }
+  for (; i < i1; ++i, fp += 8) {
+    filter_row(fp[0], fp[1], fp[2], fp[3]);
+    if (__any(qn > kQueueSlots - BATCH - 1)) flush();
   }
   flush();
 }
@@ -195,8 +206,8 @@ __global__ __launch_bounds__(kBlock) void jaccard_levels_kernel(
     const int32_t* __restrict__ lorig, const int32_t* __restrict__ lnlev, const uint8_t* __restrict__ lplen,
     const uint64_t* __restrict__ lcat, const int32_t* __restrict__ rids, const int32_t* __restrict__ rcnt,
     const uint64_t* __restrict__ rsig, const int32_t* __restrict__ rorig, const int32_t* __restrict__ rnlev,
-    const uint8_t* __restrict__ rplen, const uint64_t* __restrict__ rcat, nsm_hit* __restrict__ hits,
-    unsigned long long* __restrict__ count, const JacLevScalars<W> p) {
+    const uint8_t* __restrict__ rplen, const uint64_t* __restrict__ rcat, const uint32_t* __restrict__ lfilt,
+    nsm_hit* __restrict__ hits, unsigned long long* __restrict__ count, const JacLevScalars<W> p) {
   __shared__ uint16_t s_queue[kWavesPerBlock][kQueueSlots * kWave];
   __shared__ double s_quot[kQuotTable<W> ? (W + 1) * (2 * W + 1) : 1];
   if constexpr (kQuotTable<W>) {
@@ -242,7 +253,7 @@ __global__ __launch_bounds__(kBlock) void jaccard_levels_kernel(
   const int cls = (nbmax + NBS - 1) / NBS;
 #define NSM_LEV_CASE(K)                                                                               \
   levels_wave<W, (K) * NBS>(lids, lcnt, lsig, lorig, lnlev, lplen, lcat, rplen_row, hits, count, p, r, sr, \
-                            catr, lr, pr1, jorig, valid, i0, i1, s_queue[wave], s_quot, lane)
+                            catr, lr, pr1, jorig, valid, i0, i1, s_queue[wave], s_quot, lfilt, lane)
   switch (cls) {
     case 0:
     case 1: NSM_LEV_CASE(1); break;
@@ -297,8 +308,8 @@ int launch_levels(const nsm_set_table* l, const nsm_set_table* r, double thresho
     return NSM_E_UNSUPPORTED;
   }
   hipLaunchKernelGGL((jaccard_levels_kernel<W>), grid, dim3(kBlock), 0, stream, l->ids, l->cnt, l->sig, l->orig,
-                     l->nlev, l->plen, l->cat, r->ids, r->cnt, r->sig, r->orig, r->nlev, r->plen, r->cat, hits,
-                     hit_count, p);
+                     l->nlev, l->plen, l->cat, r->ids, r->cnt, r->sig, r->orig, r->nlev, r->plen, r->cat, l->filt,
+                     hits, hit_count, p);
   return hip_status(hipGetLastError(), "jaccard_levels_kernel launch");
 }
 

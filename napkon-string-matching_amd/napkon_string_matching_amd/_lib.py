@@ -29,6 +29,7 @@ class NsmSetTable(ctypes.Structure):
         ("nlev", ctypes.c_void_p),
         ("plen", ctypes.c_void_p),
         ("cat", ctypes.c_void_p),
+        ("filt", ctypes.c_void_p),
         ("n", ctypes.c_int32),
         ("width", ctypes.c_int32),
         ("max_levels", ctypes.c_int32),

@@ -98,6 +98,7 @@ class SetTable:
     nlev: Optional[torch.Tensor] = None
     plen: Optional[torch.Tensor] = None
     cat: Optional[torch.Tensor] = None
+    filt: Optional[torch.Tensor] = None
     max_levels: int = 0
 
     # ------------------------------------------------------------------ builders
@@ -244,10 +245,23 @@ class SetTable:
         per_size = np.bincount(cnt_s, minlength=width + 1)[: width + 1]
         size_start = np.zeros(width + 2, dtype=np.int32)
         size_start[1:] = np.cumsum(per_size[::-1])
+        sig1 = signatures(ids, cnt_s)
+        filt = None
+        if nlev is not None:  # levels table: one 32-byte filter record per row
+            filt = np.zeros((n, 8), dtype=np.uint32)
+            filt[:, 0] = (sig1 & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+            filt[:, 1] = (sig1 >> np.uint64(32)).astype(np.uint32)
+            if cat is not None:
+                c = np.asarray(cat, dtype=np.uint64)[perm]
+                filt[:, 2] = (c & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+                filt[:, 3] = (c >> np.uint64(32)).astype(np.uint32)
+            filt[:, 4] = plen[perm][:, 1].astype(np.uint32) | (cnt_s.astype(np.uint32) << 8) | (
+                nlev[perm].astype(np.uint32) << 16)
         return cls(
+            filt=None if filt is None else _dev(filt, device),
             ids=_dev(ids, device),
             cnt=_dev(cnt_s, device),
-            sig=_dev(signatures(ids, cnt_s), device),
+            sig=_dev(sig1, device),
             sig2=_dev(signatures(ids, cnt_s, _GOLDEN2), device),
             orig=_dev(base[perm], device),
             side=side,
@@ -270,7 +284,7 @@ class SetTable:
             ptr(self.ids), ptr(self.cnt), ptr(self.sig), ptr(self.sig2), ptr(self.orig), ptr(self.size_start),
             ptr(self.nlev),
             ptr(self.plen),
-            ptr(self.cat), self.n, self.width, self.max_levels,
+            ptr(self.cat), ptr(self.filt), self.n, self.width, self.max_levels,
         )
 
     def nbytes(self) -> int:

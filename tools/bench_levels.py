@@ -60,7 +60,7 @@ def main():
                                                        _lib.CAT_INTERSECT_OR_BOTH_EMPTY)
     t_strs = time.perf_counter() - t0
 
-    buf = grid.HitBuffer(1 << 20, dev)
+    buf = grid.HitBuffer(1 << 16, dev)
     buf.scratch = torch.empty_like(buf.records)
     stream = torch.cuda.current_stream(dev).cuda_stream
     mode = _lib.CAT_INTERSECT_OR_BOTH_EMPTY
