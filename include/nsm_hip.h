@@ -87,8 +87,8 @@ typedef struct nsm_set_table {
  *   codes device uint8 [n][stride]  dense alphabet codes (< alphabet), padded with `alphabet`
  *   len   device int32 [n]
  *   orig  device int32 [n]          caller's row id (RAW) / unused in levels mode
- *   len_start device int32[66]      rows with len == 64 - c are [len_start[c], len_start[c+1])
- *                                   (len_start[0] = 0, len_start[65] = n); required by the RAW grid
+ *   len_start device int32[stride+2] rows with len == stride - c are [len_start[c], len_start[c+1])
+ *                                   (len_start[0] = 0, len_start[stride+1] = n); required by the RAW grid
  *   hist  device uint8 [n][32]      symbol histogram: hist[r][b] = number of code units c of row r
  *                                   with (c & 31) == b; optional (NULL: no histogram prune)
  */
@@ -99,7 +99,8 @@ typedef struct nsm_str_table {
   const int32_t* len_start;
   const uint8_t* hist;
   int32_t n;
-  int32_t stride;   /* 64 (one 64-bit word per pattern); longer strings: NSM_E_UNSUPPORTED */
+  int32_t stride;   /* 64, 128 or 256 code units per row (1, 2 or 4 words of the bit-parallel LCS),
+                       the same on both sides of a grid; anything else: NSM_E_UNSUPPORTED */
   int32_t alphabet; /* number of distinct code units, <= 255 */
 } nsm_str_table;
 

@@ -11,7 +11,7 @@
 // its own right level row (64 B, re-loaded only when its level index changes) and runs the
 // bit-parallel LCS; the double ratio and the power-of-two weighted sum follow the reference's
 // operation order.
-#include "nsm_common.hpp"
+#include "indel_wide.hpp"
 
 namespace nsm {
 
@@ -55,6 +55,7 @@ __device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
   return (static_cast<unsigned long long>(hi) << 32) | lo;
 }
 
+template <int K>
 __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
     const int32_t* __restrict__ lfirst, const int32_t* __restrict__ lnlev, const int32_t* __restrict__ lorig,
     const uint64_t* __restrict__ lcat, const int32_t* __restrict__ lsegstart, const uint8_t* __restrict__ lcodes,
@@ -62,11 +63,15 @@ __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
     const int32_t* __restrict__ rorig, const uint64_t* __restrict__ rcat, const int32_t* __restrict__ rseg,
     const uint8_t* __restrict__ rcodes, const int32_t* __restrict__ rlen, nsm_hit* __restrict__ hits,
     unsigned long long* __restrict__ count, const IndelLevParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long s_pm[];  // [wave][pm_stride]
+  // K = 1: strings <= 64 code units, text in registers; K = 2 / 4: multi-word LCS of indel_wide.hpp,
+  // text image in LDS.  LDS layout: [wave][pm_stride * K] masks | (K > 1) [wave][16 K][64] text dwords
+  extern __shared__ __attribute__((aligned(16))) unsigned long long s_pm[];
+  constexpr int kRow = kWave * K;  // bytes per string row
+  const int waves = blockDim.x >> 6;
 
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
-  const int tile = blockIdx.x * kWavesPerBlock + wave;
+  const int tile = blockIdx.x * waves + wave;
   if (tile * kWave >= p.n_right) return;
   const int j = tile * kWave + lane;
   const bool valid = j < p.n_right;
@@ -80,7 +85,8 @@ __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
   const bool partitioned = rseg != nullptr;
   const int myseg = partitioned ? rseg[jc] : 0;
 
-  unsigned long long* pm = s_pm + wave * p.pm_stride;
+  unsigned long long* pm = s_pm + wave * p.pm_stride * K;
+  uint32_t* wtext = reinterpret_cast<uint32_t*>(s_pm + waves * p.pm_stride * K) + wave * 16 * K * kWave;
   const int i0 = blockIdx.y * p.rows_per_chunk;
   const int i1 = min(p.n_left, i0 + p.rows_per_chunk);
 
@@ -105,46 +111,52 @@ __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
       if (lrow != pm_row) {
         pm_row = lrow;
         la = llen[lrow];
-        for (int c = lane; c < p.pm_stride; c += kWave) pm[c] = 0ull;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (lane < la) {
-          const unsigned c = lcodes[static_cast<size_t>(lrow) * 64 + lane];
-          atomicOr(&pm[c], 1ull << lane);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        wide_build_pm<K>(pm, p.pm_stride, lcodes + static_cast<size_t>(lrow) * kRow, la, lane);
       }
       // right level (per lane): reload the row only when its index changes
       const int rrow = rrow0 + max(0, min(s, lr - 1));
-      if (rrow != text_row) {
-        text_row = rrow;
-        const uint4* tp = reinterpret_cast<const uint4*>(rcodes + static_cast<size_t>(rrow) * 64);
+      if constexpr (K == 1) {
+        if (rrow != text_row) {
+          text_row = rrow;
+          const uint4* tp = reinterpret_cast<const uint4*>(rcodes + static_cast<size_t>(rrow) * 64);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const uint4 v = tp[q];
-          text[4 * q + 0] = v.x;
-          text[4 * q + 1] = v.y;
-          text[4 * q + 2] = v.z;
-          text[4 * q + 3] = v.w;
+          for (int q = 0; q < 4; ++q) {
+            const uint4 v = tp[q];
+            text[4 * q + 0] = v.x;
+            text[4 * q + 1] = v.y;
+            text[4 * q + 2] = v.z;
+            text[4 * q + 3] = v.w;
+          }
+          lb = rlen[rrow];
         }
-        lb = rlen[rrow];
+      } else {
+        if (__any(rrow != text_row)) {  // the LDS image is rewritten by the whole wave
+          text_row = rrow;
+          wide_store_text<K>(wtext, rcodes + static_cast<size_t>(rrow) * kRow, lane);
+          lb = rlen[rrow];
+        }
       }
-      const int nwords = (wave_max(active ? lb : 0) + 3) >> 2;
-      unsigned long long v = ~0ull;
+      const int nchars = wave_max(active ? lb : 0);
+      int lcs;
+      if constexpr (K == 1) {
+        const int nwords = (nchars + 3) >> 2;
+        unsigned long long v = ~0ull;
 #pragma unroll
-      for (int w = 0; w < 16; ++w) {
-        if (w < nwords) {
+        for (int w = 0; w < 16; ++w) {
+          if (w < nwords) {
 #pragma unroll
-          for (int b = 0; b < 4; ++b) {
-            const unsigned c = (text[w] >> (8 * b)) & 0xffu;
-            const unsigned long long m = pm[c];
-            const unsigned long long u = v & m;
-            v = lev_add64(v, u) | (v ^ u);
+            for (int b = 0; b < 4; ++b) {
+              const unsigned c = (text[w] >> (8 * b)) & 0xffu;
+              const unsigned long long m = pm[c];
+              const unsigned long long u = v & m;
+              v = lev_add64(v, u) | (v ^ u);
+            }
           }
         }
+        lcs = 64 - __popcll(v);
+      } else {
+        lcs = wide_lcs<K>(pm, wtext, nchars, lane);
       }
-      const int lcs = 64 - __popcll(v);
       factor *= 0.5;
       if (active) score += indel_score_dev(la, lb, lcs) * factor;
     }
@@ -190,8 +202,9 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
     set_error("nsm_indel_levels_grid: null argument");
     return NSM_E_BADARG;
   }
-  if (left_strings->stride != 64 || right_strings->stride != 64) {
-    set_error("nsm_indel_levels_grid: stride %d/%d unsupported (level strings longer than 64 code units)",
+  const int stride = left_strings->stride;
+  if (stride != right_strings->stride || (stride != 64 && stride != 128 && stride != 256)) {
+    set_error("nsm_indel_levels_grid: stride %d/%d unsupported (both sides 64, 128 or 256 code units)",
               left_strings->stride, right_strings->stride);
     return NSM_E_UNSUPPORTED;
   }
@@ -239,10 +252,18 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
     p.rows_per_chunk = (left->n + 65534) / 65535;
     grid.y = (left->n + p.rows_per_chunk - 1) / p.rows_per_chunk;
   }
-  const size_t lds = static_cast<size_t>(kWavesPerBlock) * p.pm_stride * 8;
-  hipLaunchKernelGGL(indel_levels_kernel, grid, dim3(kBlock), lds, static_cast<hipStream_t>(stream), left->first,
-                     left->nlev, left->orig, left->cat, left->seg_start, left_strings->codes, left_strings->len,
-                     right->first, right->nlev, right->orig, right->cat, right->seg, right_strings->codes,
-                     right_strings->len, hits, hit_count, p);
+  const int K = stride / 64;
+  const int waves = K == 4 ? 2 : 4;  // keeps the block under 64 KiB of LDS
+  dim3 grid2((n_tiles + waves - 1) / waves, grid.y);
+  const size_t lds = static_cast<size_t>(waves) * (p.pm_stride * K * 8 + (K > 1 ? 16 * K * kWave * 4 : 0));
+#define NSM_LAUNCH_LEVELS(KK)                                                                                  \
+  hipLaunchKernelGGL((indel_levels_kernel<KK>), grid2, dim3(waves * kWave), lds, static_cast<hipStream_t>(stream), \
+                     left->first, left->nlev, left->orig, left->cat, left->seg_start, left_strings->codes,     \
+                     left_strings->len, right->first, right->nlev, right->orig, right->cat, right->seg,         \
+                     right_strings->codes, right_strings->len, hits, hit_count, p)
+  if (K == 1) NSM_LAUNCH_LEVELS(1);
+  else if (K == 2) NSM_LAUNCH_LEVELS(2);
+  else NSM_LAUNCH_LEVELS(4);
+#undef NSM_LAUNCH_LEVELS
   return hip_status(hipGetLastError(), "indel_levels_kernel launch");
 }

@@ -246,6 +246,9 @@ static int pick_rows_per_chunk(int n_left, int n_tiles) {
   return static_cast<int>(rows);
 }
 
+int indel_raw_wide(const nsm_str_table* left, const nsm_str_table* right, double threshold, uint32_t flags,
+                   nsm_hit* hits, uint64_t capacity, unsigned long long* hit_count, hipStream_t stream);
+
 }  // namespace nsm
 
 extern "C" int nsm_indel_raw_grid(const nsm_str_table* left, const nsm_str_table* right,
@@ -256,8 +259,8 @@ extern "C" int nsm_indel_raw_grid(const nsm_str_table* left, const nsm_str_table
     set_error("nsm_indel_raw_grid: null argument");
     return NSM_E_BADARG;
   }
-  if (left->stride != 64 || right->stride != 64) {
-    set_error("nsm_indel_raw_grid: stride %d/%d unsupported (strings longer than 64 code units)",
+  if (left->stride != right->stride || (left->stride != 64 && left->stride != 128 && left->stride != 256)) {
+    set_error("nsm_indel_raw_grid: stride %d/%d unsupported (both sides 64, 128 or 256 code units)",
               left->stride, right->stride);
     return NSM_E_UNSUPPORTED;
   }
@@ -276,6 +279,9 @@ extern "C" int nsm_indel_raw_grid(const nsm_str_table* left, const nsm_str_table
     set_error("nsm_indel_raw_grid: table has a null column");
     return NSM_E_BADARG;
   }
+
+  if (left->stride != 64)
+    return indel_raw_wide(left, right, threshold, flags, hits, capacity, hit_count, static_cast<hipStream_t>(stream));
 
   IndelRawParams p;
   p.n_left = left->n; p.n_right = right->n;

@@ -26,6 +26,7 @@ import torch
 from . import _lib
 
 WIDTHS = (16, 32, 64)
+STRIDES = (64, 128, 256)  # code units per string row: 1, 2 or 4 words of the bit-parallel LCS
 MAX_LEVELS = 64
 LEFT_PAD, RIGHT_PAD = -1, -2
 _GOLDEN = np.uint32(0x9E3779B1)
@@ -39,6 +40,15 @@ def pick_width(*max_counts: int) -> int:
             return w
     raise NotImplementedError(
         f"an item has {need} distinct tokens; the HIP kernels hold one row in at most {WIDTHS[-1]} registers"
+    )
+
+
+def pick_stride(max_len: int) -> int:
+    for stride in STRIDES:
+        if max_len <= stride:
+            return stride
+    raise NotImplementedError(
+        f"a string has {max_len} code units; the Indel kernels support up to {STRIDES[-1]} (4 words of 64 bits)"
     )
 
 
@@ -328,31 +338,34 @@ class StrTable:
         cls, codes: np.ndarray, lengths: np.ndarray, alphabet: int, device, orig: Optional[np.ndarray] = None,
         sort: bool = True,
     ) -> "StrTable":
-        """From uint8 codes [n][64] (entries at positions >= len are ignored) and lengths."""
+        """From uint8 codes [n][stride], stride in {64, 128, 256} (entries at positions >= len are
+        ignored) and lengths."""
         codes = np.asarray(codes, dtype=np.uint8)
         lengths = np.asarray(lengths, dtype=np.int32)
         n, stride = codes.shape
-        if stride != 64:
-            raise NotImplementedError("the Indel kernels hold one pattern in a single 64-bit word (<= 64 code units)")
-        if n and (lengths.max() > 64 or lengths.min() < 0):
-            raise NotImplementedError("string longer than 64 code units")
+        if stride not in STRIDES:
+            raise NotImplementedError(f"string table stride {stride} not in {STRIDES}")
+        if n and (lengths.max() > stride or lengths.min() < 0):
+            raise NotImplementedError(f"string longer than its row ({stride} code units)")
         if not 1 <= alphabet <= 255:
             raise ValueError("alphabet must be in [1, 255]")
         codes = codes.copy()
-        codes[np.arange(64, dtype=np.int32)[None, :] >= lengths[:, None]] = alphabet
+        codes[np.arange(stride, dtype=np.int32)[None, :] >= lengths[:, None]] = alphabet
         if n and int(codes.max()) > alphabet:
             raise ValueError("code unit outside the alphabet")
         perm = np.argsort(-lengths, kind="stable") if sort else np.arange(n)
         base = np.arange(n, dtype=np.int32) if orig is None else np.asarray(orig, dtype=np.int32)
-        # 32-bucket symbol histogram per row (bucket = code & 31) for the exact LCS upper bound
-        hist = np.zeros((n, 32), dtype=np.uint8)
+        # 32-bucket symbol histogram per row (bucket = code & 31) for the exact LCS upper bound;
+        # counts saturate at 255, which only weakens the bound
+        hist = np.zeros((n, 32), dtype=np.int32)
         if n:
-            live = np.arange(64, dtype=np.int32)[None, :] < lengths[:, None]
+            live = np.arange(stride, dtype=np.int32)[None, :] < lengths[:, None]
             rows = np.broadcast_to(np.arange(n)[:, None], codes.shape)[live]
             np.add.at(hist, (rows, codes[live] & 31), 1)
-        # rows of length (64 - c) occupy [len_start[c], len_start[c + 1]) in the length-sorted table
-        len_start = np.zeros(66, dtype=np.int32)
-        len_start[1:] = np.cumsum(np.bincount(lengths, minlength=65)[:65][::-1])
+        hist = np.minimum(hist, 255).astype(np.uint8)
+        # rows of length (stride - c) occupy [len_start[c], len_start[c + 1]) in the length-sorted table
+        len_start = np.zeros(stride + 2, dtype=np.int32)
+        len_start[1:] = np.cumsum(np.bincount(lengths, minlength=stride + 1)[: stride + 1][::-1])
         return cls(
             hist=_dev(hist[perm], device),
             len_start=_dev(len_start, device) if sort else None,
@@ -360,24 +373,24 @@ class StrTable:
             len=_dev(lengths[perm], device),
             orig=_dev(base[perm], device),
             n=n,
-            stride=64,
+            stride=stride,
             alphabet=alphabet,
             has_empty=bool(n and lengths.min() == 0),
         )
 
     @classmethod
-    def from_strings(cls, strings: Sequence[str], alphabet: Alphabet, device, sort: bool = True) -> "StrTable":
+    def from_strings(cls, strings: Sequence[str], alphabet: Alphabet, device, sort: bool = True,
+                     stride: Optional[int] = None) -> "StrTable":
         """From already pre-processed Python strings (see ``score_functions.default_process``).
         Call ``alphabet.code`` for BOTH sides' strings before building either table, or build the
-        tables with ``encode_strings`` which does that."""
+        tables with ``encode_strings`` which does that (and picks one stride for both sides)."""
         n = len(strings)
-        codes = np.zeros((n, 64), dtype=np.uint8)
+        stride = stride or pick_stride(max((len(s) for s in strings), default=0))
+        codes = np.zeros((n, stride), dtype=np.uint8)
         lengths = np.zeros(n, dtype=np.int32)
         for k, s in enumerate(strings):
-            if len(s) > 64:
-                raise NotImplementedError(
-                    f"string {k} has {len(s)} code units; the Indel kernels support <= 64 (one 64-bit word)"
-                )
+            if len(s) > stride:
+                raise NotImplementedError(f"string {k} has {len(s)} code units > row stride {stride}")
             lengths[k] = len(s)
             for q, ch in enumerate(s):
                 codes[k, q] = alphabet.code(ch)
@@ -400,8 +413,9 @@ def encode_strings(left: Sequence[str], right: Sequence[str], device):
     for s in list(left) + list(right):
         for ch in s:
             alpha.code(ch)
-    lt = StrTable.from_strings(left, alpha, device)
-    rt = StrTable.from_strings(right, alpha, device)
+    stride = pick_stride(max((len(s) for s in list(left) + list(right)), default=0))
+    lt = StrTable.from_strings(left, alpha, device, stride=stride)
+    rt = StrTable.from_strings(right, alpha, device, stride=stride)
     # both tables must agree on the alphabet size (it is also the pad code)
     assert lt.alphabet == rt.alphabet == alpha.size
     return lt, rt
@@ -453,6 +467,7 @@ def encode_level_strings(
                 for ch in s:
                     alpha.code(ch)
 
+    stride = pick_stride(max((len(s) for items in (left_items, right_items) for lv in items for s in lv), default=0))
     use_cat = category_mode != _lib.CAT_NONE and left_cat is not None and right_cat is not None
     mode = category_mode if use_cat else _lib.CAT_NONE
     cats = {}
@@ -479,7 +494,7 @@ def encode_level_strings(
             first[k] = len(flat)
             nlev[k] = len(levels)
             flat.extend(levels)
-        table = StrTable.from_strings(flat, alpha, device, sort=False)
+        table = StrTable.from_strings(flat, alpha, device, sort=False, stride=stride)
         item = np.arange(len(items), dtype=np.int32)
         seg = seg_start = None
         if do_partition:

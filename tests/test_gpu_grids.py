@@ -149,7 +149,32 @@ def test_indel_known_answers(dev):
     for k, (_, _, want) in enumerate(pairs):
         assert abs(got[(k, k)] - want) <= FUZZY_TOL
     with pytest.raises(NotImplementedError):
-        tables.encode_strings(["x" * 65], ["y"], dev)
+        tables.encode_strings(["x" * 257], ["y"], dev)
+
+
+@pytest.mark.parametrize("hi", [100, 128, 200, 256])
+@pytest.mark.parametrize("prune", [False, True])
+def test_indel_raw_long_strings(dev, hi, prune):
+    """Strings of 65..256 code units: the multi-word LCS (stride 128 / 256)."""
+    from napkon_string_matching_amd import grid, tables
+    from oracle import native
+
+    rng = random.Random(hi)
+    alphabet = "abcdefghijklmnopqrstuvwxyz "
+    left = _rand_strings(rng, 90, alphabet, 0, hi)
+    right = _rand_strings(rng, 140, alphabet, 0, hi)
+    left[0] = "".join(rng.choice(alphabet) for _ in range(hi))
+    right[5] = left[0]
+    right[6] = left[0][: hi // 2] + "zz" + left[0][hi // 2:hi - 2]
+    right[7] = left[1]
+    lt, rt = tables.encode_strings(left, right, dev)
+    assert lt.stride == rt.stride == (128 if hi <= 128 else 256)
+    cp = lambda ss: native.csr([[ord(c) for c in s] for s in ss])
+    for thr in (0.0, 0.4, 0.6, 0.9):
+        want = native.indel_raw(cp(left), cp(right), thr, cap=1 << 16)
+        got = grid.indel_raw_grid(lt, rt, thr, prune=prune, capacity=1 << 10)
+        _same_hits(got, want, FUZZY_TOL)
+        _same_hits(got, want)
 
 
 def _nested_item(rng, vocab, max_levels, max_new, allow_empty_levels=False):
@@ -223,6 +248,32 @@ def test_indel_levels_random(dev, max_levels):
         for thr in (0.0, 0.25, 0.5):
             want = native.levels(True, cps(left), cps(right), thr, lcat, rcat, mode, cap=1 << 16)
             got = grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, capacity=1 << 11)
+            _same_hits(got, want, FUZZY_TOL)
+            _same_hits(got, want)
+
+
+@pytest.mark.parametrize("hi", [90, 230])
+def test_indel_levels_long_strings(dev, hi):
+    from napkon_string_matching_amd import _lib, grid, tables
+    from oracle import native
+
+    rng = random.Random(1000 + hi)
+    alphabet = "abcdefghij klm"
+
+    def item():
+        return ["".join(rng.choice(alphabet) for _ in range(rng.randint(0, hi))).strip() for _ in range(rng.randint(1, 4))]
+
+    left, right = [item() for _ in range(40)], [item() for _ in range(70)]
+    right[3] = list(left[2])
+    lcat = np.array([rng.choice([1, 2, 3]) for _ in left], dtype=np.uint64)
+    rcat = np.array([rng.choice([0, 1, 2]) for _ in right], dtype=np.uint64)
+    cps = lambda items: [[[ord(c) for c in s] for s in it] for it in items]
+    for mode in (_lib.CAT_NONE, _lib.CAT_INTERSECT):
+        li, ls, ri, rs = tables.encode_level_strings(left, right, dev, lcat, rcat, mode)
+        assert ls.stride == rs.stride and ls.stride >= 128
+        for thr in (0.0, 0.3, 0.6):
+            want = native.levels(True, cps(left), cps(right), thr, lcat, rcat, mode, cap=1 << 14)
+            got = grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, capacity=1 << 10)
             _same_hits(got, want, FUZZY_TOL)
             _same_hits(got, want)
 
