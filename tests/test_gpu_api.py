@@ -159,3 +159,41 @@ def test_matcher_end_to_end(golden):
     assert len(m.results["hap vs Pop"]) > 0
     analysis = m._analyse()
     assert set(analysis["hap vs Pop"]) == {"matched", "gecco"}
+
+
+def test_mesh_get_matches_and_add_tokens(golden):
+    """Row f1: MeshProvider.get_matches / MatchPreparator.add_tokens through the RAW fuzzy grid."""
+    import random
+
+    from napkon_string_matching_amd.prepare.match_preparator import MatchPreparator
+    from napkon_string_matching_amd.terminology.mesh import MeshProvider, TerminologyProvider
+    from napkon_string_matching_amd.types.questionnaire import Questionnaire
+    from oracle import terminology as oterm
+
+    refs = pd.DataFrame(golden("mesh_references.json")["references"])
+    provider = MeshProvider(None, synonyms=refs)
+    # the reference's own smoke test (tests/terminology/test_mesh.py:26-33) passes a str
+    results = provider.get_matches("Dialyse nach Entlassung")
+    assert results and "Dialyse" in results[0][1] and results[0][2] > 0
+    want = oterm.get_matches(list(refs["Id"]), list(refs["Term"]), "Dialyse nach Entlassung", 0.1)
+    assert [(a, b) for a, b, _ in results] == [(a, b) for a, b, _ in want]
+    assert all(abs(x[2] - y[2]) <= 1e-6 for x, y in zip(results, want))
+
+    rng = random.Random(4)
+    words = ["dialyse", "niere", "herz", "lunge", "fieber", "husten", "impfung", "therapie", "nach", "vor", "bei"]
+    syn = pd.DataFrame({"Id": [f"D{rng.randrange(25):03d}" for _ in range(120)],
+                        "Term": [" ".join(rng.sample(words, rng.randint(1, 4))).title() for _ in range(120)]})
+    items = [rng.sample(words, rng.randint(1, 5)) for _ in range(60)]
+    provider = MeshProvider(None, synonyms=syn)
+    got = provider.get_matches_batch(items, 0.55)
+    for term, rows in zip(items, got):
+        want = oterm.get_matches(list(syn["Id"]), list(syn["Term"]), term, 0.55)
+        assert [(a, b) for a, b, _ in rows] == [(a, b) for a, b, _ in want]
+        assert all(abs(x[2] - y[2]) <= 1e-6 for x, y in zip(rows, want))
+        assert len({a for a, _, _ in rows}) == len(rows)  # one row per Id
+    cs = Questionnaire(pd.DataFrame({"Identifier": [f"i{k}" for k in range(len(items))], "Term": items}))
+    MatchPreparator(None, TerminologyProvider(None, [provider])).add_tokens(cs, score_threshold=0.55)
+    assert list(cs["TokenMatch"])[0] == (got[0] if got[0] else None)
+    first = next(k for k, rows in enumerate(got) if rows)
+    assert cs["TokenIds"][first] == tuple(a for a, _, _ in got[first])
+    assert cs["Tokens"][first] == tuple(b for _, b, _ in got[first])
