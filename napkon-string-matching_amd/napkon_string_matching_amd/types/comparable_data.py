@@ -18,7 +18,10 @@ they are resolved on the host, in pair order, against the same blacklist / categ
 """
 from __future__ import annotations
 
+import json
 import logging
+from hashlib import md5
+from pathlib import Path
 from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -32,6 +35,7 @@ from .mapping import Mapping
 logger = logging.getLogger(__name__)
 
 PREPARE_REMOVE_SYMBOLS = "!?,.()[]:;*"  # comparable_data.py:24
+CACHE_FILE_PATTERN = "compared__score_{}.json"  # comparable_data.py:25
 COMP_COLUMN = "Compare"
 TERM = "Term"
 _INF = 1 << 30
@@ -246,28 +250,61 @@ class ComparableData:
         **kwargs,
     ) -> Comparable:
         """:69-128.  Scores at ``cache_threshold or score_threshold``, keeps ``>= score_threshold``,
-        orders by score descending.  (The reference's compare cache is keyed by a hash that embeds
-        object addresses and so never hits; no cache file is read or written here.)"""
-        del cached, cache_dir
+        orders by score descending.
+
+        Compare cache: the reference keys ``compared__score_{md5}.json`` by a hash
+        that embeds object addresses (``str(kwargs.items())`` of ``Mapping`` objects, :61-67), so it
+        never hits, and it leaves ``score_func`` out of the key.  Here the key is a stable content
+        hash (both frames, both mappings, compare column, cache threshold, score function, category
+        filter, cohort names) and the cache is only used when ``cache_dir`` is given.  The file format
+        is the reference's: ``{"left_name", "right_name", "data": [records]}`` (indent 4); like
+        upstream, a frame read back from the cache carries a fresh RangeIndex instead of pair labels.
+        """
         first = cache_threshold if cache_threshold else score_threshold
-        # the rows between `first` and `score_threshold` only ever fed the cache file: without it the
-        # result of scoring at `first` and filtering at `score_threshold` equals scoring at the max
-        first = max(first, score_threshold)
-        result = self.gen_comparable(
-            other,
-            existing_mappings_whitelist,
-            existing_mappings_blacklist,
-            *args,
-            score_threshold=first,
-            compare_column=compare_column,
-            identifier_column_left=identifier_column_left,
-            identifier_column_right=identifier_column_right,
-            **kwargs,
-        )
+        cache_file = None
+        if cached and cache_dir is not None:
+            cache_file = Path(cache_dir) / CACHE_FILE_PATTERN.format(
+                self._hash_compare_args(other, existing_mappings_whitelist, existing_mappings_blacklist,
+                                        compare_column, first, kwargs))
+        if cache_file is not None and cache_file.exists():
+            logger.info("using cached result")
+            result = Comparable.read_json(cache_file)
+        else:
+            if cache_file is None:
+                # the rows between `first` and `score_threshold` only ever fed the cache file: without
+                # it, scoring at `first` and filtering at `score_threshold` equals scoring at the max
+                first = max(first, score_threshold)
+            result = self.gen_comparable(
+                other,
+                existing_mappings_whitelist,
+                existing_mappings_blacklist,
+                *args,
+                score_threshold=first,
+                compare_column=compare_column,
+                identifier_column_left=identifier_column_left,
+                identifier_column_right=identifier_column_right,
+                **kwargs,
+            )
+            if cache_file is not None:
+                cache_file.parent.mkdir(parents=True, exist_ok=True)
+                logger.info("write cache to file")
+                result.write_json(cache_file)
         result = result[result.match_score >= score_threshold]
         logger.info("got %i filtered entries", len(result))
         result.sort_by_score()
         return result
+
+    def _hash_compare_args(self, other, whitelist, blacklist, compare_column, cache_threshold, kwargs) -> str:
+        other_csv = other.to_csv() if hasattr(other, "to_csv") else pd.DataFrame(other).to_csv(index=False)
+        parts = [
+            self.to_csv(), other_csv,
+            json.dumps(_as_mapping(whitelist).dict(), sort_keys=True),
+            json.dumps(_as_mapping(blacklist).dict(), sort_keys=True),
+            str(compare_column), repr(cache_threshold),
+            json.dumps({k: kwargs.get(k) for k in ("score_func", "filter_categories", "category_column", "left_name",
+                                                    "right_name")}, sort_keys=True, default=str),
+        ]
+        return md5("\x1f".join(parts).encode("utf-8"), usedforsecurity=False).hexdigest()
 
     def gen_comparable(
         self,

@@ -197,3 +197,29 @@ def test_mesh_get_matches_and_add_tokens(golden):
     first = next(k for k, rows in enumerate(got) if rows)
     assert cs["TokenIds"][first] == tuple(a for a, _, _ in got[first])
     assert cs["Tokens"][first] == tuple(b for _, b, _ in got[first])
+
+
+def test_compare_cache_stable_key(golden, tmp_path, monkeypatch):
+    """Row f2: the compare cache hits on identical content, misses on a different score function."""
+    from napkon_string_matching_amd.types.comparable_data import ComparableData
+    from napkon_string_matching_amd.types.questionnaire import Questionnaire
+
+    case = golden("pair_grids.json")["rand_30x40"]
+    left, right = Questionnaire(pd.DataFrame(case["left"])), Questionnaire(pd.DataFrame(case["right"]))
+    kw = dict(case["compare_kwargs"])
+    first = left.compare(right, case["whitelist"], case["blacklist"], cache_dir=tmp_path, **kw)
+    files = list(tmp_path.glob("compared__score_*.json"))
+    assert len(files) == 1
+    cached_rows = pd.DataFrame(__import__("json").loads(files[0].read_text())["data"])
+    assert (cached_rows["MatchScore"] >= kw["cache_threshold"]).all() and len(cached_rows) >= len(first)
+
+    def boom(*_a, **_k):
+        raise AssertionError("gen_comparable must not run on a cache hit")
+
+    monkeypatch.setattr(ComparableData, "gen_comparable", boom)
+    again = Questionnaire(pd.DataFrame(case["left"])).compare(
+        Questionnaire(pd.DataFrame(case["right"])), case["whitelist"], case["blacklist"], cache_dir=tmp_path, **kw)
+    assert list(again.match_score) == list(first.match_score)
+    assert list(again.dataframe()["HapIdentifier"]) == list(first.dataframe()["HapIdentifier"])
+    with pytest.raises(AssertionError):  # another score function is another key
+        left.compare(right, case["whitelist"], case["blacklist"], cache_dir=tmp_path, **{**kw, "score_func": "fuzzy_match"})
