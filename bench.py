@@ -135,23 +135,19 @@ class Workload:
         )
 
 
-def gather_hits(buf, world, device):
-    """all-gatherv of the (score, i, j) hits: counts first, then max-padded records (RCCL has no
-    native gatherv).  Returns (records [world][cap][2], counts[world])."""
+def gather_hits(buf, out, world, device, async_op=False):
+    """all-gatherv of the (score, i, j) hits.  RCCL has no native gatherv; the hit buffer carries its
+    own counter in a trailing record (grid.HitBuffer), so ONE all-gather of the max-padded storage
+    moves records and counts together.  Returns the work handle when ``async_op``."""
     import torch
     import torch.distributed as dist
 
     if dist.get_backend() != "nccl":  # gloo rehearsal: stage through host memory
-        counts = torch.empty(world, dtype=torch.int64)
-        dist.all_gather_into_tensor(counts, buf.count.cpu())
-        out = torch.empty((world * buf.records.shape[0], 2), dtype=buf.records.dtype)
-        dist.all_gather_into_tensor(out, buf.records.cpu())
-        return out.to(device).view(world, -1, 2), counts.to(device)
-    counts = torch.empty(world, dtype=torch.int64, device=device)
-    dist.all_gather_into_tensor(counts, buf.count)
-    out = torch.empty((world * buf.records.shape[0], 2), dtype=buf.records.dtype, device=device)
-    dist.all_gather_into_tensor(out, buf.records)  # concatenated along dim 0
-    return out.view(world, -1, 2), counts
+        host = torch.empty((world * buf.storage.shape[0], 2), dtype=buf.storage.dtype)
+        dist.all_gather_into_tensor(host, buf.storage.cpu())
+        out.copy_(host.view_as(out))
+        return None
+    return dist.all_gather_into_tensor(out.view(-1, 2), buf.storage, async_op=async_op)
 
 
 def cpu_baseline(work, budget_pairs):
@@ -218,20 +214,39 @@ def main():
     from napkon_string_matching_amd import grid
 
     work = Workload(args.workload, rank, world, args.rows, device)
-    buf = grid.HitBuffer(args.capacity, device)
-    buf.scratch = torch.empty_like(buf.records)
+    # two hit buffers: the all-gather of step k overlaps the grid kernel of step k+1 (RCCL runs on
+    # its own stream; the buffer is only reused after its gather has completed)
+    bufs = [grid.HitBuffer(args.capacity, device) for _ in range(2)]
+    for b in bufs:
+        b.scratch = torch.empty_like(b.records)
+    gathered = [torch.empty((world,) + tuple(b.storage.shape), dtype=b.storage.dtype, device=device) for b in bufs]
+    pending = [None, None]
+    buf = bufs[0]
     stream = torch.cuda.current_stream(device).cuda_stream
     lib = work.lib
+    step_no = [0]
 
     def step(prune=True):
-        buf.count.zero_()
-        work.launch(buf, stream, prune)
-        lib.nsm_sort_hits(buf.records.data_ptr(), buf.scratch.data_ptr(), buf.capacity, buf.count.data_ptr(), stream)
+        k = step_no[0] & 1
+        step_no[0] += 1
+        b = bufs[k]
+        if pending[k] is not None:
+            pending[k].wait()
+            pending[k] = None
+        b.count.zero_()
+        work.launch(b, stream, prune)
+        lib.nsm_sort_hits(b.records.data_ptr(), b.scratch.data_ptr(), b.capacity, b.count.data_ptr(), stream)
         if world > 1:
-            return gather_hits(buf, world, device)
-        return None
+            pending[k] = gather_hits(b, gathered[k], world, device, async_op=True)
+
+    def drain():
+        for k in (0, 1):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
 
     def fence():
+        drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(device)

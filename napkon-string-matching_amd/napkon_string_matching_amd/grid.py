@@ -46,13 +46,16 @@ def _require_gpu(device) -> torch.device:
 
 
 class HitBuffer:
-    """Caller-owned hit storage: ``capacity`` 16-byte records + the device counter."""
+    """Caller-owned hit storage: ``capacity`` 16-byte records followed by the device counter, in ONE
+    allocation -- so that the multi-GPU exchange is a single all-gather of ``storage``."""
 
     def __init__(self, capacity: int, device) -> None:
         self.capacity = int(capacity)
-        self.records = torch.empty((max(1, self.capacity), 2), dtype=torch.float64, device=device)
+        rows = max(1, self.capacity)
+        self.storage = torch.zeros((rows + 1, 2), dtype=torch.float64, device=device)
+        self.records = self.storage[:rows]
+        self.count = self.storage[rows:].view(torch.int64).view(-1)[:1]  # the trailing record's first 8 bytes
         self.scratch: Optional[torch.Tensor] = None
-        self.count = torch.zeros(1, dtype=torch.int64, device=device)
 
     def reset(self) -> None:
         self.count.zero_()
