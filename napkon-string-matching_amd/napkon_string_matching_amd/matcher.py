@@ -22,7 +22,7 @@ CONFIG_FIELD_MATCHING = "matching"
 CONFIG_VARIABLE_THRESHOLD = "variable_score_threshold"
 CONFIG_OUTPUT_DIR = "output_dir"
 CONFIG_CACHE_DIR = "cache_dir"
-RESULTS_DIR_PATTERN = "result_{score_threshold}_{compare_column}_{score_func}"
+RESULTS_FILE_PATTERN = "result_{score_threshold}_{compare_column}_{score_func}.xlsx"
 
 logger = logging.getLogger(__name__)
 
@@ -116,7 +116,14 @@ class Matcher:
             logger.info("%s\t%s", name, "\t".join(f"{k}: {v}" for k, v in item.items()))
 
     def write_results(self) -> None:
+        """``result_{score_threshold}_{compare_column}_{score_func}.xlsx`` with one sheet per cohort
+        pair (matcher.py:322-331); one CSV per cohort pair in a directory of that name when no Excel
+        engine is installed."""
         matching = self.config[CONFIG_FIELD_MATCHING]
-        name = RESULTS_DIR_PATTERN.format(**{**matching, "score_func": matching["score_func"].replace("_", "-")})
-        out_dir = Path(self.config.get(CONFIG_OUTPUT_DIR) or ".") / name
-        self.results.write_csv_dir(out_dir)
+        name = RESULTS_FILE_PATTERN.format(**{**matching, "score_func": matching["score_func"].replace("_", "-")})
+        out_dir = Path(self.config.get(CONFIG_OUTPUT_DIR) or ".")
+        try:
+            self.results.write_excel(out_dir / name)
+        except ImportError:
+            logger.warning("no Excel engine installed: writing CSV files instead")
+            self.results.write_csv_dir(out_dir / name[: -len(".xlsx")])

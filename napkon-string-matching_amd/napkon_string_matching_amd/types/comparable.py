@@ -118,6 +118,16 @@ class ComparisonResults:
 
     get_items = items
 
+    def write_excel(self, file_name, *args, **kwargs) -> None:
+        """One sheet per result key (reference: types/base/writable_excel.py:11-28, which still calls
+        the ``writer.save()`` that pandas 2 removed).  Needs an Excel engine such as openpyxl."""
+        path = Path(file_name)
+        if path.parent and not path.parent.exists():
+            path.parent.mkdir(parents=True)
+        with pd.ExcelWriter(path) as writer:  # ImportError if no engine is installed
+            for key, comp in self.results.items():
+                comp.data.to_excel(writer, sheet_name=key[:31], index=False, *args, **kwargs)
+
     def write_csv_dir(self, directory) -> None:
         """One CSV per result key (the reference's xlsx writer needs openpyxl and the
         ``writer.save()`` API pandas 2 removed; spreadsheets are out of scope here)."""
