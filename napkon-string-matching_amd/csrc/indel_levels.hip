@@ -140,25 +140,47 @@ __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
       int lcs;
       if constexpr (K == 1) {
         const int nwords = (nchars + 3) >> 2;
-        unsigned long long v = ~0ull;
+        if (la <= 32) {  // wave-uniform: 32-bit words, and / add / xor / or all issue at full rate
+          const uint32_t* pm32 = reinterpret_cast<const uint32_t*>(pm);
+          uint32_t v = ~0u;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) {
-          if (w < nwords) {
+          for (int w = 0; w < 16; ++w) {
+            if (w < nwords) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-              const unsigned c = (text[w] >> (8 * b)) & 0xffu;
-              const unsigned long long m = pm[c];
-              const unsigned long long u = v & m;
-              v = lev_add64(v, u) | (v ^ u);
+              for (int b = 0; b < 4; ++b) {
+                const unsigned c = (text[w] >> (8 * b)) & 0xffu;
+                const uint32_t m = pm32[2 * c];
+                const uint32_t u = v & m;
+                v = (v + u) | (v ^ u);
+              }
             }
           }
+          lcs = 32 - __popc(v);
+        } else {
+          unsigned long long v = ~0ull;
+#pragma unroll
+          for (int w = 0; w < 16; ++w) {
+            if (w < nwords) {
+#pragma unroll
+              for (int b = 0; b < 4; ++b) {
+                const unsigned c = (text[w] >> (8 * b)) & 0xffu;
+                const unsigned long long m = pm[c];
+                const unsigned long long u = v & m;
+                v = lev_add64(v, u) | (v ^ u);
+              }
+            }
+          }
+          lcs = 64 - __popcll(v);
         }
-        lcs = 64 - __popcll(v);
       } else {
         lcs = wide_lcs<K>(pm, wtext, nchars, lane);
       }
       factor *= 0.5;
       if (active) score += indel_score_dev(la, lb, lcs) * factor;
+      // exact early exit: the steps still to come add at most factor - 2^-steps < factor (ratios are
+      // <= 1); when no lane can reach the threshold any more the rest of the row is skipped.  The
+      // 1e-9 keeps the test safe under the rounding of the double sum.
+      if (!__any(active && (score + factor + 1e-9 >= p.threshold))) break;
     }
     const bool hit = ok && score >= p.threshold;
     if (__any(hit)) {
