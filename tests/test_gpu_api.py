@@ -223,3 +223,61 @@ def test_compare_cache_stable_key(golden, tmp_path, monkeypatch):
     assert list(again.dataframe()["HapIdentifier"]) == list(first.dataframe()["HapIdentifier"])
     with pytest.raises(AssertionError):  # another score function is another key
         left.compare(right, case["whitelist"], case["blacklist"], cache_dir=tmp_path, **{**kw, "score_func": "fuzzy_match"})
+
+
+_DIST_WORKER = r'''
+import json, os, sys
+sys.path.insert(0, {pkg!r}); sys.path.insert(0, {root!r})
+import pandas as pd, torch, torch.distributed as dist
+from napkon_string_matching_amd.types.questionnaire import Questionnaire
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+torch.cuda.set_device(0)
+case = json.load(open({fixture!r}))["rand_40x30_categories"]
+left, right = Questionnaire(pd.DataFrame(case["left"])), Questionnaire(pd.DataFrame(case["right"]))
+out = {{}}
+for func in ("intersection_vs_union", "fuzzy_match"):
+    kw = dict(case["compare_kwargs"], score_func=func, score_threshold=0.2, cache_threshold=None)
+    comp = left.compare(right, case["whitelist"], case["blacklist"], **kw)
+    out[func] = [list(map(int, comp.dataframe().index)), [float(v) for v in comp.match_score]]
+json.dump(out, open({out!r} + str(dist.get_rank()), "w"))
+dist.destroy_process_group()
+'''
+
+
+def test_sharded_compare_world2(golden, tmp_path):
+    """N > 1 path end to end: two ranks (gloo, sharing this GPU) each score their block of left rows,
+    all-gather the hits and return the same Comparable as a single process."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    from napkon_string_matching_amd.types.questionnaire import Questionnaire
+
+    root = Path(__file__).resolve().parent.parent
+    script = tmp_path / "worker.py"
+    script.write_text(_DIST_WORKER.format(pkg=str(root / "napkon-string-matching_amd"), root=str(root),
+                                          fixture=str(root / "tests" / "golden" / "pair_grids.json"),
+                                          out=str(tmp_path / "out")))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=300)
+        assert p.returncode == 0, out.decode()[-2000:]
+    case = golden("pair_grids.json")["rand_40x30_categories"]
+    left, right = Questionnaire(pd.DataFrame(case["left"])), Questionnaire(pd.DataFrame(case["right"]))
+    for func in ("intersection_vs_union", "fuzzy_match"):
+        kw = dict(case["compare_kwargs"], score_func=func, score_threshold=0.2, cache_threshold=None)
+        single = left.compare(right, case["whitelist"], case["blacklist"], **kw)
+        want = [list(map(int, single.dataframe().index)), [float(v) for v in single.match_score]]
+        assert len(want[0]) > 5
+        for rank in range(2):
+            got = json.load(open(str(tmp_path / "out") + str(rank)))[func]
+            assert got == want
