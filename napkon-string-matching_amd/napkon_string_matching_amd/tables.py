@@ -302,23 +302,52 @@ class SetTable:
 
 
 class Alphabet:
-    """Dense code units shared by both sides (<= 255 distinct symbols; the pad code is ``size``)."""
+    """Dense code units shared by both sides (<= 255 distinct symbols; the pad code is ``size``).
 
-    def __init__(self) -> None:
-        self._codes: Dict[str, int] = {}
+    Built once from every string of a grid.  Codes are assigned by DESCENDING frequency: the match
+    masks of symbols c and c' only collide in LDS when c == c' (mod 32), so the 32 most frequent
+    symbols never conflict with each other.
+    """
 
-    def code(self, ch: str) -> int:
-        got = self._codes.get(ch)
-        if got is None:
-            got = len(self._codes)
-            if got >= 255:
-                raise NotImplementedError("more than 255 distinct code units in one grid")
-            self._codes[ch] = got
-        return got
+    def __init__(self, strings: Iterable[str] = ()) -> None:
+        text = "".join(strings)
+        if text:
+            points = np.frombuffer(text.encode("utf-32-le"), dtype=np.uint32)
+            uniq, counts = np.unique(points, return_counts=True)
+            order = np.argsort(-counts, kind="stable")
+            self._points = uniq[order]
+        else:
+            self._points = np.zeros(0, dtype=np.uint32)
+        if len(self._points) > 255:
+            raise NotImplementedError("more than 255 distinct code units in one grid")
+        self._sorted_idx = np.argsort(self._points, kind="stable")
+        self._sorted_pts = self._points[self._sorted_idx]
 
     @property
     def size(self) -> int:
-        return max(1, len(self._codes))
+        return max(1, len(self._points))
+
+    def encode(self, strings: Sequence[str], stride: int):
+        """codes uint8 [n][stride] (unused slots 0) and lengths int32 [n] of ``strings``."""
+        n = len(strings)
+        lengths = np.fromiter((len(s) for s in strings), dtype=np.int32, count=n)
+        if n and int(lengths.max()) > stride:
+            k = int(np.argmax(lengths))
+            raise NotImplementedError(f"string {k} has {int(lengths[k])} code units > row stride {stride}")
+        codes = np.zeros((n, stride), dtype=np.uint8)
+        total = int(lengths.sum())
+        if total:
+            points = np.frombuffer("".join(strings).encode("utf-32-le"), dtype=np.uint32)
+            pos = np.searchsorted(self._sorted_pts, points)
+            if (pos >= len(self._sorted_pts)).any() or (self._sorted_pts[np.minimum(pos, len(self._sorted_pts) - 1)] != points).any():
+                raise ValueError("string contains a code unit the alphabet was not built with")
+            flat = self._sorted_idx[pos].astype(np.uint8)
+            starts = np.zeros(n, dtype=np.int64)
+            np.cumsum(lengths[:-1], out=starts[1:])
+            rows = np.repeat(np.arange(n, dtype=np.int64), lengths)
+            cols = np.arange(total, dtype=np.int64) - np.repeat(starts, lengths)
+            codes[rows, cols] = flat
+        return codes, lengths
 
 
 @dataclass
@@ -382,18 +411,10 @@ class StrTable:
     def from_strings(cls, strings: Sequence[str], alphabet: Alphabet, device, sort: bool = True,
                      stride: Optional[int] = None) -> "StrTable":
         """From already pre-processed Python strings (see ``score_functions.default_process``).
-        Call ``alphabet.code`` for BOTH sides' strings before building either table, or build the
-        tables with ``encode_strings`` which does that (and picks one stride for both sides)."""
-        n = len(strings)
+        ``alphabet`` must have been built from BOTH sides' strings (``encode_strings`` does that and
+        picks one stride for both sides)."""
         stride = stride or pick_stride(max((len(s) for s in strings), default=0))
-        codes = np.zeros((n, stride), dtype=np.uint8)
-        lengths = np.zeros(n, dtype=np.int32)
-        for k, s in enumerate(strings):
-            if len(s) > stride:
-                raise NotImplementedError(f"string {k} has {len(s)} code units > row stride {stride}")
-            lengths[k] = len(s)
-            for q, ch in enumerate(s):
-                codes[k, q] = alphabet.code(ch)
+        codes, lengths = alphabet.encode(strings, stride)
         return cls.from_codes(codes, lengths, alphabet.size, device, sort=sort)
 
     def struct(self) -> _lib.NsmStrTable:
@@ -409,10 +430,7 @@ class StrTable:
 
 def encode_strings(left: Sequence[str], right: Sequence[str], device):
     """Both sides of a RAW fuzzy grid over one shared alphabet."""
-    alpha = Alphabet()
-    for s in list(left) + list(right):
-        for ch in s:
-            alpha.code(ch)
+    alpha = Alphabet(list(left) + list(right))
     stride = pick_stride(max((len(s) for s in list(left) + list(right)), default=0))
     lt = StrTable.from_strings(left, alpha, device, stride=stride)
     rt = StrTable.from_strings(right, alpha, device, stride=stride)
@@ -460,13 +478,7 @@ def encode_level_strings(
     predicate from a per-lane mask test -- which saves nothing, a wavefront of 64 unrelated items
     almost always contains one that matches -- into not visiting the other ~(1 - k/C) of the grid.
     """
-    alpha = Alphabet()
-    for items in (left_items, right_items):
-        for levels in items:
-            for s in levels:
-                for ch in s:
-                    alpha.code(ch)
-
+    alpha = Alphabet(s for items in (left_items, right_items) for levels in items for s in levels)
     stride = pick_stride(max((len(s) for items in (left_items, right_items) for lv in items for s in lv), default=0))
     use_cat = category_mode != _lib.CAT_NONE and left_cat is not None and right_cat is not None
     mode = category_mode if use_cat else _lib.CAT_NONE
