@@ -177,25 +177,27 @@ class SetTable:
         n = len(items)
         orders: List[List[int]] = []
         plens: List[List[int]] = []
+        ids_of = vocab._ids  # token -> id, filled in place (one dict lookup per token)
         for k, levels in enumerate(items):
             if len(levels) > MAX_LEVELS:
                 raise NotImplementedError(f"item {k} has {len(levels)} levels > {MAX_LEVELS}")
             seen: Dict[int, None] = {}
             pl: List[int] = []
             for level in levels:
-                before = len(seen)
-                distinct = 0
-                ids_here = {vocab.id(tok) for tok in level}
+                here = []
                 for tok in level:
-                    seen.setdefault(vocab.id(tok), None)
-                distinct = len(ids_here)
-                if distinct != len(seen):
+                    got = ids_of.get(tok)
+                    if got is None:
+                        got = len(ids_of)
+                        ids_of[tok] = got
+                    here.append(got)
+                seen.update(dict.fromkeys(here))
+                if len(set(here)) != len(seen):
                     # some earlier id is missing from this level: not suffix-nested
                     raise NotImplementedError(
                         f"item {k}: level {len(pl)} does not contain level {len(pl) - 1}; only "
                         "suffix-nested levels (what gen_comp_value produces) are supported on the GPU"
                     )
-                del before
                 pl.append(len(seen))
             orders.append(list(seen))
             plens.append(pl)

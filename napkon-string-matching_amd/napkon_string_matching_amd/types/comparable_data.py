@@ -77,6 +77,29 @@ class Tokenizer:
         kept = {w for w in words if w.casefold() not in self.stop_words and w not in PREPARE_REMOVE_SYMBOLS}
         return sorted(kept, key=str.casefold)
 
+    @property
+    def compositional(self) -> bool:
+        """True when tokenising a blank-joined sequence equals concatenating the parts' tokens
+        (whitespace splitting): the suffix levels can then be built incrementally."""
+        return self.word_tokenize is str.split
+
+    def levels(self, items) -> List[List[str]]:
+        """``[tokenize(items[-k:]) for k in 1..len(items)]`` (gen_comp_value, :283-285).  For a
+        compositional tokenizer each entry is tokenised once and the suffix sets grow by union --
+        the same lists, without the O(L^2) re-tokenisation."""
+        if not self.compositional or isinstance(items, str):
+            return [self(items[-k:]) for k in range(1, len(items) + 1)]
+        out: List[List[str]] = []
+        acc: set = set()
+        for entry in reversed(items):
+            parts = entry if isinstance(entry, list) else [entry]
+            for part in parts:
+                for w in part.split():
+                    if w.casefold() not in self.stop_words and w not in PREPARE_REMOVE_SYMBOLS:
+                        acc.add(w)
+            out.append(sorted(acc, key=str.casefold))
+        return out
+
 
 # =============================================================================== mappings
 def get_identifiers_from_mapping(mappings: Mapping, group: str) -> List[str]:
@@ -202,7 +225,7 @@ class ComparableData:
     @classmethod
     def gen_comp_value(cls, items) -> List[List[str]]:
         """Level l = tokens of the last l+1 entries (:283-285)."""
-        return [cls.tokenize(items[-k:]) for k in range(1, len(items) + 1)]
+        return cls.tokenizer.levels(items)
 
     @staticmethod
     def gen_term(*items: str) -> List[str]:
@@ -539,7 +562,7 @@ def _levels_grid(plugin, levels_l, levels_r, threshold, cat_l, cat_r, cat_mode=_
     dev = torch.device("cuda", torch.cuda.current_device())
     if plugin.kind == "sets":
         vocab = tables.Vocabulary()
-        as_sets = lambda items: [[list(score_functions.set_operand(lv)) for lv in it] for it in items]
+        as_sets = lambda items: [[lv if isinstance(lv, list) else lv.split() for lv in it] for it in items]
         sl, sr = as_sets(levels_l), as_sets(levels_r)
         width = tables.pick_width(
             max((len(set(it[-1])) for it in sl if it), default=1), max((len(set(it[-1])) for it in sr if it), default=1)
