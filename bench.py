@@ -44,6 +44,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=("c2", "c3"), default="c2")
     ap.add_argument("--rows", type=int, default=0, help="override rows per side per GPU (debug)")
+    ap.add_argument("--right-rows", type=int, default=0, help="override the right side's rows (debug)")
+    ap.add_argument("--threshold", type=float, default=None, help="override the workload's threshold (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--capacity", type=int, default=1 << 13)
     ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
@@ -54,7 +56,7 @@ def parse_args():
 class Workload:
     """Operand tables in HBM + the launch closure of one workload."""
 
-    def __init__(self, name, rank, world, rows, device):
+    def __init__(self, name, rank, world, rows, device, right_rows=0, threshold=None):
         import numpy as np
         import torch
 
@@ -65,8 +67,8 @@ class Workload:
         self.flag_prune = _lib.FLAG_PRUNE
         if name == "c2":
             n = rows or 50_000
-            m = rows or 50_000
-            self.threshold = 0.5
+            m = right_rows or rows or 50_000
+            self.threshold = 0.5 if threshold is None else threshold
             # global left corpus = world * n rows; this rank scores rows [rank*n, (rank+1)*n)
             left = synthetic.token_sets(n, 1234 + 1000 * rank)
             right = synthetic.token_sets(m, 5678)
@@ -87,11 +89,11 @@ class Workload:
             self.launch_fn = self.lib.nsm_jaccard_raw_grid
             self.kernel = "jaccard_raw_kernel<16>"
             self.dtype = "int32"
-            self.label = f"C2: {n}x{m} token-id sets/GPU (Poisson(8) ids, W=16), intersection_vs_union RAW, threshold 0.5"
+            self.label = f"C2: {n}x{m} token-id sets/GPU (Poisson(8) ids, W=16), intersection_vs_union RAW, threshold {self.threshold}"
         else:
             n = rows or 200_000
-            m = rows or 200_000
-            self.threshold = 0.8
+            m = right_rows or rows or 200_000
+            self.threshold = 0.8 if threshold is None else threshold
             left = synthetic.strings(n, 1234 + 1000 * rank)
             right = synthetic.strings(m, 5678)
             if rank == 0:
@@ -112,7 +114,7 @@ class Workload:
             self.launch_fn = self.lib.nsm_indel_raw_grid
             self.kernel = "indel_raw_kernel"
             self.dtype = "u64"
-            self.label = f"C3: {n}x{m} strings/GPU (len U[16,64], 37 symbols), fuzzy_match RAW, threshold 0.8"
+            self.label = f"C3: {n}x{m} strings/GPU (len U[16,64], 37 symbols), fuzzy_match RAW, threshold {self.threshold}"
         self.n, self.m = n, m
         self.ls, self.rs = self.left.struct(), self.right.struct()
 
@@ -220,7 +222,7 @@ def main():
 
     from napkon_string_matching_amd import grid
 
-    work = Workload(args.workload, rank, world, args.rows, device)
+    work = Workload(args.workload, rank, world, args.rows, device, args.right_rows, args.threshold)
     # two hit buffers: the all-gather of step k overlaps the grid kernel of step k+1 (RCCL runs on
     # its own stream; the buffer is only reused after its gather has completed)
     bufs = [grid.HitBuffer(args.capacity, device) for _ in range(2)]

@@ -7,9 +7,10 @@
 // launch geometry comes from `capacity` and every kernel reads the count itself:
 //   * up to 2048 live records (the common case): ONE workgroup sorts 128-bit integer keys
 //     (~score bits, i, j) with a bitonic network in LDS and writes the records back in place;
-//   * up to 128 Ki records of capacity: rank sort -- each record counts its predecessors in one pass
-//     over LDS-staged tiles and is scattered to scratch[rank]; no inter-block dependency;
-//   * larger: bitonic network in global memory, "flip" form (all comparators point the same way),
+//   * up to 8192 live records: rank sort -- each record counts its predecessors in one pass over
+//     LDS-staged tiles and is scattered to scratch[rank]; no inter-block dependency (O(n^2): 52 k
+//     records took 7 ms, hence the limit);
+//   * more: bitonic network in global memory, "flip" form (all comparators point the same way),
 //     which needs no padding to a power of two; passes beyond the live count exit immediately.
 #include "nsm_common.hpp"
 
@@ -28,6 +29,7 @@ __device__ __forceinline__ unsigned long long live_count(const unsigned long lon
 }
 
 constexpr int kSmallSortMax = 2048;
+constexpr unsigned long long kRankSortMax = 8192;
 constexpr int kSmallSortThreads = 1024;
 
 // Order-preserving integer image of a double, inverted: larger score -> smaller key.
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(kBlock) void rank_sort_kernel(const nsm_hit* __rest
                                                            const unsigned long long* __restrict__ count) {
   __shared__ nsm_hit tile[kBlock];
   const unsigned long long n = live_count(count, capacity);
-  if (n <= kSmallSortMax) return;  // small_sort_kernel's job
+  if (n <= kSmallSortMax || n > kRankSortMax) return;  // small_sort_kernel's / the bitonic passes' job
   const unsigned long long base = static_cast<unsigned long long>(blockIdx.x) * kBlock;
   if (base >= n) return;  // whole block
   const unsigned long long idx = base + threadIdx.x;
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(kBlock) void copy_hits_kernel(const nsm_hit* __rest
                                                            unsigned long long capacity,
                                                            const unsigned long long* __restrict__ count) {
   const unsigned long long n = live_count(count, capacity);
-  if (n <= kSmallSortMax) return;  // sorted in place by small_sort_kernel
+  if (n <= kSmallSortMax || n > kRankSortMax) return;  // sorted in place by the other kernels
   for (unsigned long long idx = static_cast<unsigned long long>(blockIdx.x) * kBlock + threadIdx.x; idx < n;
        idx += static_cast<unsigned long long>(gridDim.x) * kBlock)
     dst[idx] = src[idx];
@@ -129,7 +131,8 @@ __global__ __launch_bounds__(kBlock) void bitonic_pass_kernel(nsm_hit* __restric
                                                               const unsigned long long* __restrict__ count,
                                                               unsigned long long k, unsigned long long j) {
   const unsigned long long n = live_count(count, capacity);
-  if ((k >> 1) >= n) return;  // merges larger than the (virtually padded) list do nothing
+  if (n <= kRankSortMax) return;  // the LDS / rank sorts handled it
+  if ((k >> 1) >= n) return;      // merges larger than the (virtually padded) list do nothing
   for (unsigned long long idx = static_cast<unsigned long long>(blockIdx.x) * kBlock + threadIdx.x; idx < n;
        idx += static_cast<unsigned long long>(gridDim.x) * kBlock) {
     const unsigned long long partner = j == 0 ? (idx ^ (k - 1)) : (idx ^ j);
@@ -144,7 +147,6 @@ __global__ __launch_bounds__(kBlock) void bitonic_pass_kernel(nsm_hit* __restric
   }
 }
 
-constexpr unsigned long long kRankSortMax = 1ull << 17;
 
 }  // namespace nsm
 
@@ -157,19 +159,19 @@ extern "C" int nsm_sort_hits(nsm_hit* hits, nsm_hit* scratch, uint64_t capacity,
   }
   if (capacity == 0) return 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (capacity <= kRankSortMax) {
-    if (!scratch) {
-      set_error("nsm_sort_hits: scratch buffer required");
-      return NSM_E_BADARG;
-    }
-    const unsigned blocks = static_cast<unsigned>((capacity + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(small_sort_kernel, dim3(1), dim3(kSmallSortThreads), 0, s, hits, capacity, hit_count);
-    if (capacity <= kSmallSortMax) return hip_status(hipGetLastError(), "nsm_sort_hits (small)");
-    hipLaunchKernelGGL(rank_sort_kernel, dim3(blocks), dim3(kBlock), 0, s, hits, scratch, capacity, hit_count);
-    hipLaunchKernelGGL(copy_hits_kernel, dim3(blocks < 1024 ? blocks : 1024), dim3(kBlock), 0, s, scratch, hits,
-                       capacity, hit_count);
-    return hip_status(hipGetLastError(), "nsm_sort_hits (rank sort)");
+  hipLaunchKernelGGL(small_sort_kernel, dim3(1), dim3(kSmallSortThreads), 0, s, hits, capacity, hit_count);
+  if (capacity <= kSmallSortMax) return hip_status(hipGetLastError(), "nsm_sort_hits (small)");
+  if (!scratch) {
+    set_error("nsm_sort_hits: scratch buffer required");
+    return NSM_E_BADARG;
   }
+  {
+    const unsigned long long live_max = capacity < kRankSortMax ? capacity : kRankSortMax;
+    const unsigned blocks = static_cast<unsigned>((live_max + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(rank_sort_kernel, dim3(blocks), dim3(kBlock), 0, s, hits, scratch, capacity, hit_count);
+    hipLaunchKernelGGL(copy_hits_kernel, dim3(blocks), dim3(kBlock), 0, s, scratch, hits, capacity, hit_count);
+  }
+  if (capacity <= kRankSortMax) return hip_status(hipGetLastError(), "nsm_sort_hits (rank sort)");
   unsigned long long blocks64 = (capacity + kBlock - 1) / kBlock;
   const unsigned blocks = static_cast<unsigned>(blocks64 < 8192 ? blocks64 : 8192);
   for (unsigned long long k = 2; (k >> 1) < capacity; k <<= 1) {

@@ -18,6 +18,8 @@
 //     skips the matrix unless some lane can reach kmin under two independent signatures;
 //   * exact size filter: a whole size class is skipped when kmin > min(|A|, |B|) for every lane.
 #pragma once
+#include <cmath>
+
 #include "nsm_common.hpp"
 
 namespace nsm {
@@ -31,6 +33,7 @@ struct JacRawScalars {
   int32_t rows_per_chunk;
   unsigned long long cap;
   uint8_t kmin[2 * W + 4];  // indexed by |A|+|B|
+  unsigned long long weak[W + 1];  // weak[|A|] bit |B|: the signature bound rarely fails for these sizes
 };
 
 // Wave-uniform value -> VGPR.  On gfx950 a VALU op with an SGPR source issues at half rate
@@ -85,7 +88,7 @@ __device__ __forceinline__ void class_rows(const int32_t* __restrict__ lids,
                                            nsm_hit* __restrict__ hits, unsigned long long cap,
                                            unsigned long long* __restrict__ count,
                                            const uint32_t (&r)[W], int nrj, uint64_t sr, uint64_t sr2,
-                                           int jorig, int a, int b, int nl, int need) {
+                                           int jorig, int a, int b, int nl, int need, bool use_prune) {
   auto exact_row = [&](int i) {
     const int k = NL - nonmatches<W, NL, NB>(lids + static_cast<size_t>(i) * W, r);
     const bool hit = k >= need;
@@ -96,7 +99,7 @@ __device__ __forceinline__ void class_rows(const int32_t* __restrict__ lids,
       }
     }
   };
-  if constexpr (PRUNE) {
+  if (PRUNE && use_prune) {
     // |A n B| <= popcount(hashbits(A) & hashbits(B)) + cA.  A signature word holds 58 hash bits and,
     // in its top 6 bits, cA = the ids of the row that share a hash bit with an earlier id of the
     // same row (|A| - popcount(hashbits)): common ids that collide inside the row are the only ones
@@ -167,7 +170,8 @@ __device__ __forceinline__ void wave_rows(const int32_t* __restrict__ lids,
                                           nsm_hit* __restrict__ hits, unsigned long long cap,
                                           unsigned long long* __restrict__ count,
                                           const uint32_t (&r)[W], int nrj, uint64_t sr, uint64_t sr2,
-                                          int jorig, bool valid, int i0, int i1, const uint8_t* s_kmin) {
+                                          int jorig, bool valid, int i0, int i1, const uint8_t* s_kmin,
+                                          const unsigned long long* p_weak) {
   constexpr int NLS = W / 4;  // left size classes: NLS, 2 NLS, 3 NLS, W
   // rows are sorted by size (descending): rows of size W - c are [lstart[c], lstart[c + 1]); the
   // chunk [i0, i1) only touches the sizes between its first and its last row
@@ -181,8 +185,14 @@ __device__ __forceinline__ void wave_rows(const int32_t* __restrict__ lids,
     const int need = valid ? s_kmin[nl + nrj] : kNever;
     // exact size filter: a pair can only reach the threshold if kmin <= min(|A|, |B|)
     if (!__any(need <= min(nl, nrj))) continue;
-#define NSM_ROWS(NL) \
-  class_rows<W, NL, NB, PRUNE>(lids, lsig, lsig2, lorig, hits, cap, count, r, nrj, sr, sr2, jorig, a, b, nl, need)
+    // The signature bound only pays when it fails for (nearly) every lane of the wave; the launcher
+    // marks the size pairs for which a random pair passes it too often (low thresholds) and such a
+    // class runs without the prune.
+    const bool weak = valid && nrj < 64 && ((p_weak[nl] >> nrj) & 1ull);
+    const bool use_prune = !__any(weak);
+#define NSM_ROWS(NL)                                                                                        \
+  class_rows<W, NL, NB, PRUNE>(lids, lsig, lsig2, lorig, hits, cap, count, r, nrj, sr, sr2, jorig, a, b, nl, need, \
+                               use_prune)
     switch ((nl + NLS - 1) / NLS) {
       case 0: {  // empty left sets: no common id, hit only when kmin == 0 (threshold <= 0)
         const bool hit = need == 0;
@@ -245,7 +255,7 @@ __global__ __launch_bounds__(kBlock) void jaccard_raw_kernel(
   constexpr int NBS = W / 8;  // right size classes: NBS, 2 NBS, ..., W
   const int cls = (nbmax + NBS - 1) / NBS;
 #define NSM_WAVE(K) \
-  wave_rows<W, (K) * NBS, PRUNE>(lids, lcnt, lstart, lsig, lsig2, lorig, hits, p.cap, count, r, nrj, sr, sr2, jorig, valid, i0, i1, s_kmin)
+  wave_rows<W, (K) * NBS, PRUNE>(lids, lcnt, lstart, lsig, lsig2, lorig, hits, p.cap, count, r, nrj, sr, sr2, jorig, valid, i0, i1, s_kmin, p.weak)
   switch (cls) {
     case 0:
     case 1: NSM_WAVE(1); break;
@@ -294,6 +304,22 @@ int launch_raw(const nsm_set_table* l, const nsm_set_table* r, double threshold,
   JacRawScalars<W> p;
   p.n_left = l->n; p.n_right = r->n; p.cap = capacity;
   fill_kmin<W>(p.kmin, threshold);
+  // weak[nl] bit nr: two random sets of nl and nr ids share ~Poisson(nl*nr/58) hash bits; when the
+  // chance of reaching kmin that way exceeds 1/128 a wave of 64 lanes passes more often than not
+  for (int a = 0; a <= W; ++a) {
+    p.weak[a] = 0;
+    for (int b = 0; b <= W && b < 64; ++b) {
+      const int need = p.kmin[a + b];
+      if (need == kNever || need > (a < b ? a : b)) continue;
+      const double mu = static_cast<double>(a) * b / 58.0;
+      double term = std::exp(-mu), below = 0.0;  // P(X < need)
+      for (int k = 0; k < need; ++k) {
+        below += term;
+        term *= mu / (k + 1);
+      }
+      if (1.0 - below > 1.0 / 128.0) p.weak[a] |= 1ull << b;
+    }
+  }
   const int n_tiles = (r->n + kWave - 1) / kWave;
   p.rows_per_chunk = jac_rows_per_chunk(l->n, n_tiles);
   dim3 grid((n_tiles + kWavesPerBlock - 1) / kWavesPerBlock,
