@@ -64,6 +64,9 @@ typedef struct nsm_hit {
  *   nlev  device int32 [n]         number of levels L (>= 1)
  *   plen  device uint8 [n][max_levels]  level l = the first plen[l] ids of the row (non-decreasing)
  *   cat   device uint64[n]         category bit mask, NULL when categories are not filtered
+ *   seg, seg_start                 category partition exactly as in nsm_level_items (below): both NULL, or
+ *                                  set on both sides together with NSM_CAT_INTERSECT; rows sorted by seg,
+ *                                  then by cnt descending
  *   filt  device uint32[n][8]      filter record of the row: {sig lo, sig hi, cat lo, cat hi,
  *                                  plen[min(1,L-1)] | cnt << 8 | nlev << 16, 0, 0, 0} (one s_load per 2 rows)
  */
@@ -78,6 +81,8 @@ typedef struct nsm_set_table {
   const uint8_t* plen;
   const uint64_t* cat;
   const uint32_t* filt;
+  const int32_t* seg;
+  const int32_t* seg_start;
   int32_t n;
   int32_t width;      /* 16, 32 or 64 */
   int32_t max_levels; /* row stride of plen */

@@ -45,6 +45,12 @@ extern "C" int nsm_jaccard_levels_grid(const nsm_set_table* left, const nsm_set_
       return NSM_E_BADARG;
     }
   }
+  if ((left->seg == nullptr) != (right->seg == nullptr) ||
+      (left->seg && (!left->seg_start || category_mode != NSM_CAT_INTERSECT))) {
+    set_error("nsm_jaccard_levels_grid: a category partition needs seg/seg_start on both sides and "
+              "NSM_CAT_INTERSECT");
+    return NSM_E_BADARG;
+  }
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (left->width) {
     case 16: return launch_levels<16>(left, right, threshold, category_mode, flags, hits, capacity, hit_count, s);

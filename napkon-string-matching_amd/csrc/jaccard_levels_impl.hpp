@@ -56,6 +56,16 @@ __device__ __forceinline__ uint32_t lev_min3u(uint32_t a, uint32_t b, uint32_t c
   return d;
 }
 
+__device__ __forceinline__ unsigned long long lev_wave_or64(unsigned long long v) {
+  uint32_t lo = static_cast<uint32_t>(v), hi = static_cast<uint32_t>(v >> 32);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo |= __shfl_xor(lo, off, kWave);
+    hi |= __shfl_xor(hi, off, kWave);
+  }
+  return (static_cast<unsigned long long>(hi) << 32) | lo;
+}
+
 __device__ __forceinline__ int lev_wave_max(int v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, kWave));
@@ -69,7 +79,8 @@ __device__ __forceinline__ void levels_wave(
     const uint64_t* __restrict__ lcat, const uint8_t* __restrict__ rplen_row, nsm_hit* __restrict__ hits,
     unsigned long long* __restrict__ count, const JacLevScalars<W>& p, const uint32_t (&r)[W], uint64_t sr,
     uint64_t catr, int lr, int pr1, int jorig, bool valid, int i0, int i1, uint16_t* queue,
-    const double* quot, const uint32_t* __restrict__ lfilt, int lane) {
+    const double* quot, const uint32_t* __restrict__ lfilt, const int32_t* __restrict__ lsegstart, bool partitioned,
+    int myseg, int lane) {
   int qn = 0;  // candidates queued by this lane
   const int bneed_r = static_cast<int>((p.bneed >> (4 * min(pr1, 15))) & 15ull);
 
@@ -166,12 +177,18 @@ __device__ __forceinline__ void levels_wave(
   uint32_t rowv = 0;                                  // row offset inside the chunk, in a VGPR
   const uint32_t qbase = static_cast<uint32_t>(lane * 2);  // byte offset of the lane's queue column
 
+  // category partition: while the rows of category c stream by, only lanes standing for c take part
+  // and a pair is dropped when the two items also share a LOWER category (it is reported there)
+  bool seg_ok = true;
+  uint32_t lower_lo = 0, lower_hi = 0;  // catr restricted to the categories below c
   auto filter_row = [&](uint32_t sig_lo, uint32_t sig_hi, uint32_t cat_lo, uint32_t cat_hi) {
     int bound;
     asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(bound) : "v"(sig_lo & sr_lo), "s"(sig_hi >> 26));
     asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(bound) : "v"(sig_hi & sr_hi), "v"(bound));
     bool pass = bound >= need_r;
-    if (use_cat) {
+    if (partitioned) {
+      pass = pass && seg_ok && (((cat_lo & lower_lo) | (cat_hi & lower_hi)) == 0u);
+    } else if (use_cat) {
       const uint32_t common = (cat_lo & catr_lo) | (cat_hi & catr_hi);
       bool cat_ok = common != 0u;
       if (both_empty) cat_ok = cat_ok || ((cat_lo | cat_hi | catr_lo | catr_hi) == 0u);
@@ -183,19 +200,39 @@ __device__ __forceinline__ void levels_wave(
     rowv += 1;
   };
 
-  const uint32_t* __restrict__ fp = lfilt + static_cast<size_t>(i0) * 8;
-  int i = i0;
-  for (; i + BATCH <= i1; i += BATCH, fp += 8 * BATCH) {
-    uint32_t f[8 * BATCH];
+  auto filter_range = [&](int a, int b) {  // rows [a, b) of the chunk
+    rowv = static_cast<uint32_t>(a - i0);
+    const uint32_t* __restrict__ fp = lfilt + static_cast<size_t>(a) * 8;
+    int i = a;
+    for (; i + BATCH <= b; i += BATCH, fp += 8 * BATCH) {
+      uint32_t f[8 * BATCH];
 #pragma unroll
-    for (int q = 0; q < 8 * BATCH; ++q) f[q] = fp[q];
+      for (int q = 0; q < 8 * BATCH; ++q) f[q] = fp[q];
 #pragma unroll
-    for (int q = 0; q < BATCH; ++q) filter_row(f[8 * q + 0], f[8 * q + 1], f[8 * q + 2], f[8 * q + 3]);
-    if (__any(qn > kQueueSlots - BATCH - 1)) flush();
-  }
-  for (; i < i1; ++i, fp += 8) {
-    filter_row(fp[0], fp[1], fp[2], fp[3]);
-    if (__any(qn > kQueueSlots - BATCH - 1)) flush();
+      for (int q = 0; q < BATCH; ++q) filter_row(f[8 * q + 0], f[8 * q + 1], f[8 * q + 2], f[8 * q + 3]);
+      if (__any(qn > kQueueSlots - BATCH - 1)) flush();
+    }
+    for (; i < b; ++i, fp += 8) {
+      filter_row(fp[0], fp[1], fp[2], fp[3]);
+      if (__any(qn > kQueueSlots - BATCH - 1)) flush();
+    }
+  };
+
+  if (partitioned) {
+    unsigned long long cats = lev_wave_or64(valid ? (1ull << myseg) : 0ull);
+    while (cats) {
+      const int c = __builtin_ctzll(cats);
+      cats &= cats - 1;
+      const unsigned long long lower = catr & ((1ull << c) - 1ull);
+      lower_lo = static_cast<uint32_t>(lower);
+      lower_hi = static_cast<uint32_t>(lower >> 32);
+      seg_ok = myseg == c;
+      const int a = max(i0, lsegstart[c]);
+      const int b = min(i1, lsegstart[c + 1]);
+      if (a < b) filter_range(a, b);
+    }
+  } else {
+    filter_range(i0, i1);
   }
   flush();
 }
@@ -207,7 +244,7 @@ __global__ __launch_bounds__(kBlock) void jaccard_levels_kernel(
     const uint64_t* __restrict__ lcat, const int32_t* __restrict__ rids, const int32_t* __restrict__ rcnt,
     const uint64_t* __restrict__ rsig, const int32_t* __restrict__ rorig, const int32_t* __restrict__ rnlev,
     const uint8_t* __restrict__ rplen, const uint64_t* __restrict__ rcat, const uint32_t* __restrict__ lfilt,
-    nsm_hit* __restrict__ hits, unsigned long long* __restrict__ count, const JacLevScalars<W> p) {
+    const int32_t* __restrict__ lsegstart, const int32_t* __restrict__ rseg, nsm_hit* __restrict__ hits, unsigned long long* __restrict__ count, const JacLevScalars<W> p) {
   __shared__ uint16_t s_queue[kWavesPerBlock][kQueueSlots * kWave];
   __shared__ double s_quot[kQuotTable<W> ? (W + 1) * (2 * W + 1) : 1];
   if constexpr (kQuotTable<W>) {
@@ -244,7 +281,9 @@ __global__ __launch_bounds__(kBlock) void jaccard_levels_kernel(
   const int jorig = rorig[jc];
   const uint8_t* rplen_row = rplen + static_cast<size_t>(jc) * p.lev_stride_r;
   const int pr1 = rplen_row[1];
-  const int nbmax = wave_first(nrj);
+  const int nbmax = lev_wave_max(nrj);  // (with a category partition lane 0 is not the largest)
+  const bool partitioned = rseg != nullptr;
+  const int myseg = partitioned ? rseg[jc] : 0;
 
   const int i0 = blockIdx.y * p.rows_per_chunk;
   const int i1 = min(p.n_left, i0 + p.rows_per_chunk);
@@ -253,7 +292,7 @@ __global__ __launch_bounds__(kBlock) void jaccard_levels_kernel(
   const int cls = (nbmax + NBS - 1) / NBS;
 #define NSM_LEV_CASE(K)                                                                               \
   levels_wave<W, (K) * NBS>(lids, lcnt, lsig, lorig, lnlev, lplen, lcat, rplen_row, hits, count, p, r, sr, \
-                            catr, lr, pr1, jorig, valid, i0, i1, s_queue[wave], s_quot, lfilt, lane)
+                            catr, lr, pr1, jorig, valid, i0, i1, s_queue[wave], s_quot, lfilt, lsegstart, partitioned, myseg, lane)
   switch (cls) {
     case 0:
     case 1: NSM_LEV_CASE(1); break;
@@ -309,7 +348,7 @@ int launch_levels(const nsm_set_table* l, const nsm_set_table* r, double thresho
   }
   hipLaunchKernelGGL((jaccard_levels_kernel<W>), grid, dim3(kBlock), 0, stream, l->ids, l->cnt, l->sig, l->orig,
                      l->nlev, l->plen, l->cat, r->ids, r->cnt, r->sig, r->orig, r->nlev, r->plen, r->cat, l->filt,
-                     hits, hit_count, p);
+                     l->seg_start, r->seg, hits, hit_count, p);
   return hip_status(hipGetLastError(), "jaccard_levels_kernel launch");
 }
 

@@ -30,6 +30,8 @@ class NsmSetTable(ctypes.Structure):
         ("plen", ctypes.c_void_p),
         ("cat", ctypes.c_void_p),
         ("filt", ctypes.c_void_p),
+        ("seg", ctypes.c_void_p),
+        ("seg_start", ctypes.c_void_p),
         ("n", ctypes.c_int32),
         ("width", ctypes.c_int32),
         ("max_levels", ctypes.c_int32),

@@ -147,6 +147,8 @@ def jaccard_levels_grid(
     lib = _lib.load()
     ls, rs = left.struct(), right.struct()
     flags = _lib.FLAG_PRUNE if prune else 0
+    if left.category_mode is not None:  # the encoder may have rewritten the predicate (partition)
+        category_mode = left.category_mode
 
     def launch(buf: HitBuffer, stream: int) -> int:
         return lib.nsm_jaccard_levels_grid(

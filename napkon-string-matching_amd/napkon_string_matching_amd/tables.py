@@ -29,6 +29,7 @@ WIDTHS = (16, 32, 64)
 STRIDES = (64, 128, 256)  # code units per string row: 1, 2 or 4 words of the bit-parallel LCS
 MAX_LEVELS = 64
 LEFT_PAD, RIGHT_PAD = -1, -2
+EMPTY_CATEGORY_BIT = 63  # stands for "no category at all" when empty-vs-empty counts as a match
 _GOLDEN = np.uint32(0x9E3779B1)
 _GOLDEN2 = np.uint32(0xC2B2AE35)
 
@@ -110,6 +111,9 @@ class SetTable:
     cat: Optional[torch.Tensor] = None
     filt: Optional[torch.Tensor] = None
     max_levels: int = 0
+    seg: Optional[torch.Tensor] = None
+    seg_start: Optional[torch.Tensor] = None
+    category_mode: Optional[int] = None  # the mode the levels kernel must be called with (set by the encoder)
 
     # ------------------------------------------------------------------ builders
     @classmethod
@@ -171,6 +175,8 @@ class SetTable:
         vocab: Vocabulary,
         width: Optional[int] = None,
         categories: Optional[np.ndarray] = None,
+        category_mode: int = _lib.CAT_NONE,
+        partition: bool = True,
     ) -> "SetTable":
         """Levels table.  ``items[k]`` is the level list of item k (``gen_comp_value`` output,
         types/comparable_data.py:283-285): level l must contain level l-1 (suffix nesting)."""
@@ -215,12 +221,14 @@ class SetTable:
             if pl:
                 plen[k, len(pl):] = pl[-1]
         cnt = (ids >= 0).sum(axis=1).astype(np.int32)
-        return cls._finish(ids, cnt, side, device, width, None, nlev=nlev, plen=plen, cat=categories, max_levels=max_levels)
+        return cls._finish(ids, cnt, side, device, width, None, nlev=nlev, plen=plen, cat=categories,
+                           max_levels=max_levels, category_mode=category_mode, partition=partition)
 
     @classmethod
     def from_nested_arrays(
         cls, ids: np.ndarray, plen: np.ndarray, nlev: np.ndarray, side: str, device,
         categories: Optional[np.ndarray] = None, width: Optional[int] = None,
+        category_mode: int = _lib.CAT_NONE, partition: bool = True,
     ) -> "SetTable":
         """Levels table from arrays that already are in suffix-nested layout: ``ids`` [n][w] unique
         per row (negative = padding, valid ids first), ``plen`` [n][L] non-decreasing prefix lengths,
@@ -240,18 +248,46 @@ class SetTable:
         if plen.shape[1] < max_levels:  # pad with the last value (clamped level index)
             plen = np.concatenate([plen, np.repeat(plen[:, -1:], max_levels - plen.shape[1], axis=1)], axis=1)
         return cls._finish(ids, cnt, side, device, width, None, nlev=np.asarray(nlev, dtype=np.int32), plen=plen,
-                           cat=categories, max_levels=max_levels)
+                           cat=categories, max_levels=max_levels, category_mode=category_mode, partition=partition)
 
     @classmethod
-    def _finish(cls, ids, cnt, side, device, width, orig, nlev=None, plen=None, cat=None, max_levels=0):
+    def _finish(cls, ids, cnt, side, device, width, orig, nlev=None, plen=None, cat=None, max_levels=0,
+                category_mode=_lib.CAT_NONE, partition=False):
         if side not in ("left", "right"):
             raise ValueError("side must be 'left' or 'right'")
         n = ids.shape[0]
         ids = ids.copy()
         pad = LEFT_PAD if side == "left" else RIGHT_PAD
         ids[np.arange(width, dtype=np.int32)[None, :] >= cnt[:, None]] = pad
-        perm = np.argsort(-cnt, kind="stable")  # size descending, ties by input order
         base = np.arange(n, dtype=np.int32) if orig is None else np.asarray(orig, dtype=np.int32)
+        seg = seg_start = None
+        mode = category_mode if (nlev is not None and cat is not None) else _lib.CAT_NONE
+        if cat is not None:
+            cat = np.asarray(cat, dtype=np.uint64).copy()
+        if mode != _lib.CAT_NONE and partition:
+            # Category partition (see encode_level_strings): an item with k categories becomes k rows,
+            # rows are grouped per category; "both empty" becomes one more category of the empty items.
+            if mode == _lib.CAT_INTERSECT_OR_BOTH_EMPTY:
+                if n and int(cat.max()) >> EMPTY_CATEGORY_BIT:
+                    partition = False
+                else:
+                    cat[cat == 0] = np.uint64(1) << np.uint64(EMPTY_CATEGORY_BIT)
+                    mode = _lib.CAT_INTERSECT
+        if mode != _lib.CAT_NONE and partition:
+            rows, segs = [], []
+            for c in range(64):
+                has = np.flatnonzero((cat >> np.uint64(c)) & np.uint64(1))
+                rows.append(has)
+                segs.append(np.full(len(has), c, dtype=np.int32))
+            rows = np.concatenate(rows).astype(np.int64)
+            seg = np.concatenate(segs)
+            order = np.lexsort((-cnt[rows], seg))  # per category: larger sets first
+            perm, seg = rows[order], seg[order]
+            seg_start = np.zeros(65, dtype=np.int32)
+            seg_start[1:] = np.cumsum(np.bincount(seg, minlength=64)[:64])
+            n = len(perm)
+        else:
+            perm = np.argsort(-cnt, kind="stable")  # size descending, ties by input order
         ids, cnt_s = ids[perm], cnt[perm]
         # rows of size (width - c) occupy [size_start[c], size_start[c + 1]) in the sorted table
         per_size = np.bincount(cnt_s, minlength=width + 1)[: width + 1]
@@ -264,7 +300,7 @@ class SetTable:
             filt[:, 0] = (sig1 & np.uint64(0xFFFFFFFF)).astype(np.uint32)
             filt[:, 1] = (sig1 >> np.uint64(32)).astype(np.uint32)
             if cat is not None:
-                c = np.asarray(cat, dtype=np.uint64)[perm]
+                c = cat[perm]
                 filt[:, 2] = (c & np.uint64(0xFFFFFFFF)).astype(np.uint32)
                 filt[:, 3] = (c >> np.uint64(32)).astype(np.uint32)
             filt[:, 4] = plen[perm][:, 1].astype(np.uint32) | (cnt_s.astype(np.uint32) << 8) | (
@@ -283,8 +319,11 @@ class SetTable:
             size_start=_dev(size_start, device),
             nlev=None if nlev is None else _dev(nlev[perm], device),
             plen=None if plen is None else _dev(plen[perm], device),
-            cat=None if cat is None else _dev(np.asarray(cat, dtype=np.uint64)[perm], device),
+            cat=None if cat is None else _dev(cat[perm], device),
             max_levels=max_levels,
+            seg=None if seg is None else _dev(seg, device),
+            seg_start=None if seg_start is None else _dev(seg_start, device),
+            category_mode=mode if nlev is not None else None,
         )
 
     # ------------------------------------------------------------------ C view
@@ -296,7 +335,7 @@ class SetTable:
             ptr(self.ids), ptr(self.cnt), ptr(self.sig), ptr(self.sig2), ptr(self.orig), ptr(self.size_start),
             ptr(self.nlev),
             ptr(self.plen),
-            ptr(self.cat), ptr(self.filt), self.n, self.width, self.max_levels,
+            ptr(self.cat), ptr(self.filt), ptr(self.seg), ptr(self.seg_start), self.n, self.width, self.max_levels,
         )
 
     def nbytes(self) -> int:
@@ -462,9 +501,6 @@ class LevelItems:
             self.first.data_ptr(), self.nlev.data_ptr(), self.orig.data_ptr(), ptr(self.cat), ptr(self.seg),
             ptr(self.seg_start), self.n,
         )
-
-
-EMPTY_CATEGORY_BIT = 63  # stands for "no category at all" when empty-vs-empty counts as a match
 
 
 def encode_level_strings(

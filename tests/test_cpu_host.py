@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.nsm_abi_version() == _lib.ABI_VERSION
     # struct layouts must match the header (sizes on LP64)
     assert ctypes.sizeof(_lib.NsmHit) == 16
-    assert ctypes.sizeof(_lib.NsmSetTable) == 10 * 8 + 3 * 4 + 4
+    assert ctypes.sizeof(_lib.NsmSetTable) == 12 * 8 + 3 * 4 + 4
     assert ctypes.sizeof(_lib.NsmStrTable) == 5 * 8 + 3 * 4 + 4
     assert ctypes.sizeof(_lib.NsmLevelItems) == 6 * 8 + 4 + 4
 
@@ -48,8 +48,8 @@ def test_argument_validation_without_gpu():
     if not _lib.LIB_PATH.exists():
         pytest.skip("libnsm_hip.so not built")
     lib = _lib.load()
-    a = _lib.NsmSetTable(None, None, None, None, None, None, None, None, None, None, 3, 16, 0)
-    b = _lib.NsmSetTable(None, None, None, None, None, None, None, None, None, None, 3, 32, 0)
+    a = _lib.NsmSetTable(None, None, None, None, None, None, None, None, None, None, None, None, 3, 16, 0)
+    b = _lib.NsmSetTable(None, None, None, None, None, None, None, None, None, None, None, None, 3, 32, 0)
     cnt = ctypes.c_ulonglong(0)
     rc = lib.nsm_jaccard_raw_grid(a, b, 0.5, 0, None, 0, ctypes.addressof(cnt), None)
     assert rc == 10001 and b"width" in lib.nsm_last_error()

@@ -85,7 +85,7 @@ def test_c5_shaped_levels_properties(dev):
     pop = synthetic.c5_cohort(n, 12, plant_from=hap)
     mode = _lib.CAT_INTERSECT_OR_BOTH_EMPTY
     mk = lambda c, side: tables.SetTable.from_nested_arrays(c["ids"], c["plen"], c["nlev"], side, dev,
-                                                             categories=c["cat"], width=16)
+                                                             categories=c["cat"], width=16, category_mode=mode)
     # self grid: every item matches itself with the maximal score 1 - 2^-4
     self_hits = grid.jaccard_levels_grid(mk(hap, "left"), mk(hap, "right"), 0.9, category_mode=mode)
     diag = {(i, j) for s, i, j in self_hits.as_tuples() if i == j}
@@ -95,6 +95,11 @@ def test_c5_shaped_levels_properties(dev):
     tok_index = {tuple(r): k for k, r in enumerate(map(tuple, hap["tok"]))}
     planted = [(tok_index[tuple(r)], j) for j, r in enumerate(map(tuple, pop["tok"])) if tuple(r) in tok_index]
     assert len(planted) >= 200 and all(p in same for p in planted)
+    # the category-partitioned grid and the per-lane predicate agree
+    mk2 = lambda c, side: tables.SetTable.from_nested_arrays(c["ids"], c["plen"], c["nlev"], side, dev,
+                                                              categories=c["cat"], width=16, category_mode=mode,
+                                                              partition=False)
+    assert grid.jaccard_levels_grid(mk2(hap, "left"), mk2(pop, "right"), 0.7, category_mode=mode).as_tuples() == hits
     # fuzzy levels on a 6k corner: partitioned == unpartitioned
     m = 6000
     lv = lambda c: [[sf.fuzzy_operand(x) for x in it] for it in synthetic.c5_level_token_lists(c, slice(0, m))]

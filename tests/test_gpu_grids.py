@@ -198,12 +198,16 @@ def test_jaccard_levels_random(dev, vocab, max_levels, max_new):
     right = [_nested_item(rng, vocab, max_levels, max_new) for _ in range(310)]
     lcat = np.array([rng.choice([0, 1, 2, 3, 6]) for _ in left], dtype=np.uint64)
     rcat = np.array([rng.choice([0, 1, 2, 4, 5]) for _ in right], dtype=np.uint64)
-    vocabulary = tables.Vocabulary()
     width = tables.pick_width(max(len(it[-1]) for it in left + right))
-    lt = tables.SetTable.from_levels(left, "left", dev, vocabulary, width=width, categories=lcat)
-    rt = tables.SetTable.from_levels(right, "right", dev, vocabulary, width=width, categories=rcat)
-    for thr in (0.0, 0.1, 0.3, 0.6):
-        for mode in (_lib.CAT_NONE, _lib.CAT_INTERSECT, _lib.CAT_INTERSECT_OR_BOTH_EMPTY):
+    for mode, partition in ((_lib.CAT_NONE, True), (_lib.CAT_INTERSECT, True), (_lib.CAT_INTERSECT_OR_BOTH_EMPTY, True),
+                            (_lib.CAT_INTERSECT_OR_BOTH_EMPTY, False)):
+        vocabulary = tables.Vocabulary()
+        lt = tables.SetTable.from_levels(left, "left", dev, vocabulary, width=width, categories=lcat,
+                                         category_mode=mode, partition=partition)
+        rt = tables.SetTable.from_levels(right, "right", dev, vocabulary, width=width, categories=rcat,
+                                         category_mode=mode, partition=partition)
+        assert (lt.seg is not None) == (partition and mode != _lib.CAT_NONE)
+        for thr in (0.0, 0.1, 0.3, 0.6):
             want = native.levels(False, left, right, thr, lcat, rcat, mode, cap=1 << 17)
             got = grid.jaccard_levels_grid(lt, rt, thr, category_mode=mode, capacity=1 << 12)
             _same_hits(got, want)

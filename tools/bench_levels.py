@@ -48,7 +48,8 @@ def main():
     for nm, c in cohorts.items():
         for side in ("left", "right"):
             set_tables[nm, side] = tables.SetTable.from_nested_arrays(
-                c["ids"], c["plen"], c["nlev"], side, dev, categories=c["cat"], width=16)
+                c["ids"], c["plen"], c["nlev"], side, dev, categories=c["cat"], width=16,
+                category_mode=_lib.CAT_INTERSECT_OR_BOTH_EMPTY)
     t_sets = time.perf_counter() - t0
     t0 = time.perf_counter()
     level_strings = {nm: [[sf.fuzzy_operand(lv) for lv in it] for it in synthetic.c5_level_token_lists(c)]
@@ -68,7 +69,7 @@ def main():
     def run_jaccard(a, b):
         buf.count.zero_()
         _lib.check(lib.nsm_jaccard_levels_grid(set_tables[a, "left"].struct(), set_tables[b, "right"].struct(),
-                                               args.threshold, mode, 1, buf.records.data_ptr(), buf.capacity,
+                                               args.threshold, set_tables[a, "left"].category_mode, 1, buf.records.data_ptr(), buf.capacity,
                                                buf.count.data_ptr(), stream), "jaccard_levels")
         lib.nsm_sort_hits(buf.records.data_ptr(), buf.scratch.data_ptr(), buf.capacity, buf.count.data_ptr(), stream)
 
@@ -108,9 +109,11 @@ def main():
             ids = lambda items: [[[vocab.setdefault(t, len(vocab)) for t in lv] for lv in it] for it in items]
             want = native.levels(False, ids(la), ids(lb), args.threshold, cohorts[a]["cat"][:m], cohorts[b]["cat"][:m], 2)
             sub_l = tables.SetTable.from_nested_arrays(cohorts[a]["ids"][:m], cohorts[a]["plen"][:m], cohorts[a]["nlev"][:m],
-                                                       "left", dev, categories=cohorts[a]["cat"][:m], width=16)
+                                                       "left", dev, categories=cohorts[a]["cat"][:m], width=16,
+                                                       category_mode=mode)
             sub_r = tables.SetTable.from_nested_arrays(cohorts[b]["ids"][:m], cohorts[b]["plen"][:m], cohorts[b]["nlev"][:m],
-                                                       "right", dev, categories=cohorts[b]["cat"][:m], width=16)
+                                                       "right", dev, categories=cohorts[b]["cat"][:m], width=16,
+                                                       category_mode=mode)
             got = grid.jaccard_levels_grid(sub_l, sub_r, args.threshold, category_mode=mode).as_tuples()
             assert got == want, (a, b, len(got), len(want))
             sl = [[sf.fuzzy_operand(lv) for lv in it] for it in la]
