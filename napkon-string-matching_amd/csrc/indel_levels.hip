@@ -77,18 +77,28 @@ __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
   const bool valid = j < p.n_right;
   const int jc = valid ? j : p.n_right - 1;
 
+  const bool partitioned = rseg != nullptr;
+  const int myseg = partitioned ? rseg[jc] : 0;
+  const int i0 = blockIdx.y * p.rows_per_chunk;
+  const int i1 = min(p.n_left, i0 + p.rows_per_chunk);
+  if (partitioned) {  // most (tile, chunk) combinations hold no row of the tile's categories: leave early
+    unsigned long long cats = wave_or64(valid ? (1ull << myseg) : 0ull);
+    bool work = false;
+    while (cats) {
+      const int c = __builtin_ctzll(cats);
+      cats &= cats - 1;
+      work = work || (max(i0, lsegstart[c]) < min(i1, lsegstart[c + 1]));
+    }
+    if (!work) return;
+  }
+
   const int lr = rnlev[jc];
   const int rrow0 = rfirst[jc];
   const int jorig = rorig[jc];
   const uint64_t catr = (p.cat_mode != NSM_CAT_NONE) ? rcat[jc] : 0ull;
   const int lr_max = wave_max(valid ? lr : 0);
-  const bool partitioned = rseg != nullptr;
-  const int myseg = partitioned ? rseg[jc] : 0;
-
   unsigned long long* pm = s_pm + wave * p.pm_stride * K;
   uint32_t* wtext = reinterpret_cast<uint32_t*>(s_pm + waves * p.pm_stride * K) + wave * 16 * K * kWave;
-  const int i0 = blockIdx.y * p.rows_per_chunk;
-  const int i1 = min(p.n_left, i0 + p.rows_per_chunk);
 
   uint32_t text[16];
   int text_row = -1;
@@ -268,6 +278,9 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
   long long rows = (left->n + chunks - 1) / chunks;
   if (rows < 32) rows = 32;
   if (rows > 4096) rows = 4096;
+  // with a category partition a tile only works on the chunks that overlap its categories' row
+  // ranges: small chunks, or a handful of long-running waves hold the whole launch
+  if (left->seg && rows > 128) rows = 128;
   p.rows_per_chunk = static_cast<int>(rows);
   dim3 grid((n_tiles + kWavesPerBlock - 1) / kWavesPerBlock, (left->n + p.rows_per_chunk - 1) / p.rows_per_chunk);
   if (grid.y > 65535) {

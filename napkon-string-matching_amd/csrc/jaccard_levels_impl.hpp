@@ -264,6 +264,21 @@ __global__ __launch_bounds__(kBlock) void jaccard_levels_kernel(
   const bool valid = j < p.n_right;
   const int jc = valid ? j : p.n_right - 1;
 
+  const bool partitioned = rseg != nullptr;
+  const int myseg = partitioned ? rseg[jc] : 0;
+  const int i0 = blockIdx.y * p.rows_per_chunk;
+  const int i1 = min(p.n_left, i0 + p.rows_per_chunk);
+  if (partitioned) {  // most (tile, chunk) combinations hold no row of the tile's categories: leave early
+    unsigned long long cats = lev_wave_or64(valid ? (1ull << myseg) : 0ull);
+    bool work = false;
+    while (cats) {
+      const int c = __builtin_ctzll(cats);
+      cats &= cats - 1;
+      work = work || (max(i0, lsegstart[c]) < min(i1, lsegstart[c + 1]));
+    }
+    if (!work) return;
+  }
+
   uint32_t r[W];
   const uint4* rp = reinterpret_cast<const uint4*>(rids + static_cast<size_t>(jc) * W);
 #pragma unroll
@@ -282,11 +297,6 @@ __global__ __launch_bounds__(kBlock) void jaccard_levels_kernel(
   const uint8_t* rplen_row = rplen + static_cast<size_t>(jc) * p.lev_stride_r;
   const int pr1 = rplen_row[1];
   const int nbmax = lev_wave_max(nrj);  // (with a category partition lane 0 is not the largest)
-  const bool partitioned = rseg != nullptr;
-  const int myseg = partitioned ? rseg[jc] : 0;
-
-  const int i0 = blockIdx.y * p.rows_per_chunk;
-  const int i1 = min(p.n_left, i0 + p.rows_per_chunk);
 
   constexpr int NBS = W / 8;
   const int cls = (nbmax + NBS - 1) / NBS;
@@ -341,6 +351,9 @@ int launch_levels(const nsm_set_table* l, const nsm_set_table* r, double thresho
   }
   const int n_tiles = (r->n + kWave - 1) / kWave;
   p.rows_per_chunk = lev_rows_per_chunk(l->n, n_tiles);
+  // with a category partition a tile only works on the chunks that overlap its categories' row
+  // ranges: small chunks, or a handful of long-running waves hold the whole launch
+  if (l->seg && p.rows_per_chunk > 512) p.rows_per_chunk = 512;
   dim3 grid((n_tiles + kWavesPerBlock - 1) / kWavesPerBlock, (l->n + p.rows_per_chunk - 1) / p.rows_per_chunk);
   if (grid.y > 65535) {
     set_error("nsm_jaccard_levels_grid: more than 65535 * 4096 left rows");
