@@ -10,7 +10,6 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence, Tuple
 
-import numpy as np
 import pandas as pd
 
 from ..compare import score_functions

@@ -214,3 +214,45 @@ def test_all_gather_hits_gloo_world2(tmp_path):
     for p in procs:
         out, _ = p.communicate(timeout=240)
         assert p.returncode == 0, out.decode()
+
+
+def test_category_partition_encoding_cpu():
+    """The host side of the category partition: rows per category, lowest-common-category dedupe is
+    the kernel's job, 'both empty' becomes category 63."""
+    from napkon_string_matching_amd import _lib, tables
+
+    cat = np.array([0b101, 0, 0b010, 0b100], dtype=np.uint64)
+    items = [[["a"]], [["b"]], [["c"], ["c", "d"]], [["e"]]]
+    v = tables.Vocabulary()
+    t = tables.SetTable.from_levels(items, "left", "cpu", v, categories=cat, category_mode=_lib.CAT_INTERSECT_OR_BOTH_EMPTY)
+    assert t.category_mode == _lib.CAT_INTERSECT and t.n == 5  # item 0 twice, the empty item in category 63
+    assert t.seg.tolist() == [0, 1, 2, 2, 63]
+    assert sorted(t.orig[t.seg == 2].tolist()) == [0, 3] and t.orig[-1].item() == 1
+    ss = t.seg_start.tolist()
+    assert ss[0] == 0 and ss[1] == 1 and ss[2] == 2 and ss[3] == 4 and ss[63] == 4 and ss[64] == 5
+    assert t.filt.shape == (5, 8)
+    plain = tables.SetTable.from_levels(items, "left", "cpu", v, categories=cat, category_mode=_lib.CAT_INTERSECT_OR_BOTH_EMPTY,
+                                        partition=False)
+    assert plain.seg is None and plain.n == 4 and plain.category_mode == _lib.CAT_INTERSECT_OR_BOTH_EMPTY
+    none = tables.SetTable.from_levels(items, "left", "cpu", v)
+    assert none.category_mode == _lib.CAT_NONE and none.cat is None
+    li, ls, ri, rs = tables.encode_level_strings([["ab"], ["c"]], [["ab"]], "cpu", cat[:2], cat[:1], _lib.CAT_INTERSECT)
+    assert li.seg.tolist() == [0, 2] and li.n == 2 and ri.seg.tolist() == [0, 2]  # the empty item is dropped
+
+
+def test_results_writers(tmp_path):
+    from napkon_string_matching_amd.matcher import Matcher
+    from napkon_string_matching_amd.types.comparable import Comparable, ComparisonResults
+
+    frame = pd.DataFrame({"HapIdentifier": ["h0"], "PopIdentifier": ["p0"], "HapVariable": ["gec_a"],
+                          "PopVariable": ["x"], "MatchScore": [0.9]}, index=[4])
+    res = ComparisonResults({"hap vs pop": Comparable(frame, "Hap", "Pop")})
+    res.write_csv_dir(tmp_path / "csv")
+    assert (tmp_path / "csv" / "hap_vs_pop.csv").read_text().startswith(",HapIdentifier")
+    m = Matcher(None, {"matching": {"score_threshold": 0.7, "compare_column": "Term", "score_func": "fuzzy_match"},
+                       "output_dir": str(tmp_path)})
+    m.results = res
+    m.write_results()  # xlsx if an engine is installed, else the CSV directory
+    produced = list(tmp_path.glob("result_0.7_Term_fuzzy-match*"))
+    assert produced
+    assert m._analyse() == {"hap vs pop": {"matched": "1/1", "gecco": "0/1"}}
