@@ -64,12 +64,7 @@ def signatures(ids: np.ndarray, cnt: np.ndarray, multiplier: np.uint32 = _GOLDEN
     pos = ((h16.astype(np.uint64) * np.uint64(58)) >> np.uint64(16)).astype(np.uint64)
     bits = np.where(valid, np.uint64(1) << pos, np.uint64(0))
     word = np.bitwise_or.reduce(bits, axis=1)
-    pop = np.zeros(n, dtype=np.int64)
-    tmp = word.copy()
-    for _ in range(58):
-        pop += (tmp & np.uint64(1)).astype(np.int64)
-        tmp >>= np.uint64(1)
-    extra = np.minimum(63, cnt.astype(np.int64) - pop).astype(np.uint64)
+    extra = np.minimum(63, cnt.astype(np.int64) - np.bitwise_count(word).astype(np.int64)).astype(np.uint64)
     return word | (extra << np.uint64(58))
 
 
@@ -354,15 +349,17 @@ class Alphabet:
         text = "".join(strings)
         if text:
             points = np.frombuffer(text.encode("utf-32-le"), dtype=np.uint32)
-            uniq, counts = np.unique(points, return_counts=True)
-            order = np.argsort(-counts, kind="stable")
-            self._points = uniq[order]
+            counts = np.bincount(points)  # at most 0x110000 bins
+            uniq = np.flatnonzero(counts)
+            order = np.argsort(-counts[uniq], kind="stable")
+            self._points = uniq[order].astype(np.uint32)
         else:
             self._points = np.zeros(0, dtype=np.uint32)
         if len(self._points) > 255:
             raise NotImplementedError("more than 255 distinct code units in one grid")
-        self._sorted_idx = np.argsort(self._points, kind="stable")
-        self._sorted_pts = self._points[self._sorted_idx]
+        # code point -> code (255 = not in the alphabet; codes are < 255)
+        self._lut = np.full(int(self._points.max(initial=0)) + 2, 255, dtype=np.uint8)
+        self._lut[self._points] = np.arange(len(self._points), dtype=np.uint8)
 
     @property
     def size(self) -> int:
@@ -379,15 +376,11 @@ class Alphabet:
         total = int(lengths.sum())
         if total:
             points = np.frombuffer("".join(strings).encode("utf-32-le"), dtype=np.uint32)
-            pos = np.searchsorted(self._sorted_pts, points)
-            if (pos >= len(self._sorted_pts)).any() or (self._sorted_pts[np.minimum(pos, len(self._sorted_pts) - 1)] != points).any():
+            flat = self._lut[np.minimum(points, len(self._lut) - 1)]
+            if len(self._points) == 0 or (flat == 255).any():
                 raise ValueError("string contains a code unit the alphabet was not built with")
-            flat = self._sorted_idx[pos].astype(np.uint8)
-            starts = np.zeros(n, dtype=np.int64)
-            np.cumsum(lengths[:-1], out=starts[1:])
-            rows = np.repeat(np.arange(n, dtype=np.int64), lengths)
-            cols = np.arange(total, dtype=np.int64) - np.repeat(starts, lengths)
-            codes[rows, cols] = flat
+            # row-major order of the live slots == concatenation order of the strings
+            codes[np.arange(stride, dtype=np.int32)[None, :] < lengths[:, None]] = flat
         return codes, lengths
 
 
@@ -427,11 +420,11 @@ class StrTable:
         base = np.arange(n, dtype=np.int32) if orig is None else np.asarray(orig, dtype=np.int32)
         # 32-bucket symbol histogram per row (bucket = code & 31) for the exact LCS upper bound;
         # counts saturate at 255, which only weakens the bound
-        hist = np.zeros((n, 32), dtype=np.int32)
+        hist = np.zeros((n, 32), dtype=np.int64)
         if n:
             live = np.arange(stride, dtype=np.int32)[None, :] < lengths[:, None]
-            rows = np.broadcast_to(np.arange(n)[:, None], codes.shape)[live]
-            np.add.at(hist, (rows, codes[live] & 31), 1)
+            slot = (np.arange(n, dtype=np.int64)[:, None] * 32 + (codes & 31))[live]
+            hist = np.bincount(slot, minlength=n * 32).reshape(n, 32)
         hist = np.minimum(hist, 255).astype(np.uint8)
         # rows of length (stride - c) occupy [len_start[c], len_start[c + 1]) in the length-sorted table
         len_start = np.zeros(stride + 2, dtype=np.int32)
