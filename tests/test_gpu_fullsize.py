@@ -109,3 +109,65 @@ def test_c5_shaped_levels_properties(dev):
         li, ls, ri, rs = tables.encode_level_strings(la, lb, dev, hap["cat"][:m], pop["cat"][:m], mode, partition=part)
         res.append(grid.indel_levels_grid(li, ls, ri, rs, 0.7, category_mode=mode).as_tuples())
     assert res[0] == res[1] and len(res[0]) > 0
+
+
+def test_c4_full_size_sharded_equals_whole(dev):
+    """configs[3]: 1M x 1M token-id sets, threshold 0.8.  The eight left-row blocks of the 8-GPU
+    layout, run one after the other here, reproduce the one-grid result; prune == no prune."""
+    from napkon_string_matching_amd import distributed, grid, synthetic, tables
+    from oracle import score_functions as osf
+
+    n = 1_000_000
+    left, right = synthetic.c2_corpus(n, n)
+    rt = tables.SetTable.from_padded(right, "right", dev)
+    whole = _tuples(grid.jaccard_raw_grid(tables.SetTable.from_padded(left, "left", dev), rt, 0.8))
+    assert len(whole) >= 2000
+    parts = []
+    for rank in range(8):
+        lo, hi = distributed.shard_bounds(n, rank, 8)
+        block = tables.SetTable.from_padded(left[lo:hi], "left", dev, orig=np.arange(lo, hi, dtype=np.int32))
+        got = grid.jaccard_raw_grid(block, rt, 0.8)
+        assert all(lo <= i < hi for i in got.i.tolist())
+        parts += _tuples(got)
+        if rank == 3:  # one block also exhaustively (1.25e11 pairs)
+            assert _tuples(grid.jaccard_raw_grid(block, rt, 0.8, prune=False)) == _tuples(got)
+    assert sorted(parts, key=lambda h: (-h[0], h[1], h[2])) == whole
+    for s, i, j in whole[:: max(1, len(whole) // 500)]:
+        a = [str(v) for v in left[i] if v >= 0]
+        b = [str(v) for v in right[j] if v >= 0]
+        assert s == osf.intersection_vs_union(a, b) and s >= 0.8
+
+
+def test_c5_full_size_cohort_pair(dev):
+    """configs[4]: one 500k x 500k cohort pair, 4 levels, 32 categories, filter_categories, Jaccard
+    levels at the config's score threshold 0.7: planted items found with the maximal score, the
+    category partition agrees with the per-lane predicate, hits are monotone in the threshold."""
+    from napkon_string_matching_amd import _lib, grid, synthetic, tables
+    from oracle import compare as ocmp
+    from oracle import score_functions as osf
+
+    n = 500_000
+    hap = synthetic.c5_cohort(n, 21)
+    pop = synthetic.c5_cohort(n, 22, plant_from=hap)
+    mode = _lib.CAT_INTERSECT_OR_BOTH_EMPTY
+
+    def mk(c, side, partition=True):
+        return tables.SetTable.from_nested_arrays(c["ids"], c["plen"], c["nlev"], side, dev, categories=c["cat"],
+                                                  width=16, category_mode=mode, partition=partition)
+
+    hits = grid.jaccard_levels_grid(mk(hap, "left"), mk(pop, "right"), 0.7, category_mode=mode).as_tuples()
+    plain = grid.jaccard_levels_grid(mk(hap, "left", False), mk(pop, "right", False), 0.7, category_mode=mode)
+    assert plain.as_tuples() == hits and len(hits) >= 2000
+    cached = grid.jaccard_levels_grid(mk(hap, "left"), mk(pop, "right"), 0.5, category_mode=mode).as_tuples()
+    assert [h for h in cached if h[0] >= 0.7] == hits  # cache_threshold 0.5 then score_threshold 0.7
+    tok_index = {tuple(r): k for k, r in enumerate(map(tuple, hap["tok"]))}
+    planted = [(tok_index[tuple(r)], j) for j, r in enumerate(map(tuple, pop["tok"])) if tuple(r) in tok_index]
+    same = {(i, j) for s, i, j in hits if s == 0.9375}
+    cats_ok = lambda i, j: bool(hap["cat"][i] & pop["cat"][j]) or (hap["cat"][i] == 0 and pop["cat"][j] == 0)
+    assert len(planted) >= 2000 and all(p in same for p in planted if cats_ok(*p))
+    # a sample of hits re-scored by the oracle's compare_terms on the decoded level lists
+    sample = hits[:: max(1, len(hits) // 200)]
+    for s, i, j in sample:
+        a = synthetic.c5_level_token_lists(hap, slice(i, i + 1))[0]
+        b = synthetic.c5_level_token_lists(pop, slice(j, j + 1))[0]
+        assert s == ocmp.compare_terms(a, b, osf.intersection_vs_union) and cats_ok(i, j)
