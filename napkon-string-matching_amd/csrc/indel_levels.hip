@@ -183,7 +183,7 @@ __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
           lcs = 64 - __popcll(v);
         }
       } else {
-        lcs = wide_lcs<K>(pm, wtext, nchars, lane);
+        lcs = wide_lcs<K>(pm, wtext, nchars, lane, la);
       }
       factor *= 0.5;
       if (active) score += indel_score_dev(la, lb, lcs) * factor;

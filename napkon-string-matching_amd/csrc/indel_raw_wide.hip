@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kBlock) void indel_raw_wide_kernel(
         if (!__any(static_cast<int>(l1) <= limit)) continue;
       }
       wide_build_pm<K>(pm, p.pm_stride, lcodes + static_cast<size_t>(i) * kMaxLen, la, lane);
-      const int lcs = wide_lcs<K>(pm, text, nchars, lane);
+      const int lcs = wide_lcs<K, true>(pm, text, nchars, lane, la, lbj, need);
       const bool hit = lcs >= need;
       if (__any(hit)) {
         if (hit) emit_hit(hits, p.cap, count, indel_score_wide(la, lbj, lcs), lorig[i], jorig);

@@ -51,32 +51,96 @@ __device__ __forceinline__ void wide_store_text(uint32_t* text, const uint8_t* _
   __builtin_amdgcn_wave_barrier();
 }
 
-// LCS length of the wave's pattern (masks in pm) and the lane's text (first nchars code units, the
-// wave's longest text; shorter texts are padded with the all-zero-mask symbol).
-template <int K>
-__device__ __forceinline__ int wide_lcs(const unsigned long long* pm, const uint32_t* text, int nchars, int lane) {
-  unsigned long long v[K];
+// t = v + u over W 64-bit words as one v_add_co / v_addc_co chain (the compiler's own expansion is a
+// 64-bit add, a 64-bit compare and a select per word)
+template <int W>
+__device__ __forceinline__ void add_chain(const unsigned long long (&v)[W], const unsigned long long (&u)[W],
+                                          unsigned long long (&t)[W]) {
+  uint32_t a[2 * W], b[2 * W], d[2 * W];
 #pragma unroll
-  for (int k = 0; k < K; ++k) v[k] = ~0ull;
-  for (int w = 0; 4 * w < nchars; ++w) {
+  for (int k = 0; k < W; ++k) {
+    a[2 * k] = static_cast<uint32_t>(v[k]); a[2 * k + 1] = static_cast<uint32_t>(v[k] >> 32);
+    b[2 * k] = static_cast<uint32_t>(u[k]); b[2 * k + 1] = static_cast<uint32_t>(u[k] >> 32);
+  }
+  if constexpr (W == 1) {
+    asm("v_add_co_u32 %0, vcc, %2, %4\n\tv_addc_co_u32 %1, vcc, %3, %5, vcc"
+        : "=&v"(d[0]), "=&v"(d[1]) : "v"(a[0]), "v"(a[1]), "v"(b[0]), "v"(b[1]) : "vcc");
+  } else if constexpr (W == 2) {
+    asm("v_add_co_u32 %0, vcc, %4, %8\n\tv_addc_co_u32 %1, vcc, %5, %9, vcc\n\t"
+        "v_addc_co_u32 %2, vcc, %6, %10, vcc\n\tv_addc_co_u32 %3, vcc, %7, %11, vcc"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]) : "vcc");
+  } else if constexpr (W == 3) {
+    asm("v_add_co_u32 %0, vcc, %6, %12\n\tv_addc_co_u32 %1, vcc, %7, %13, vcc\n\t"
+        "v_addc_co_u32 %2, vcc, %8, %14, vcc\n\tv_addc_co_u32 %3, vcc, %9, %15, vcc\n\t"
+        "v_addc_co_u32 %4, vcc, %10, %16, vcc\n\tv_addc_co_u32 %5, vcc, %11, %17, vcc"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5])
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(b[0]), "v"(b[1]), "v"(b[2]),
+          "v"(b[3]), "v"(b[4]), "v"(b[5]) : "vcc");
+  } else {
+    static_assert(W == 4, "1..4 words");
+    asm("v_add_co_u32 %0, vcc, %8, %16\n\tv_addc_co_u32 %1, vcc, %9, %17, vcc\n\t"
+        "v_addc_co_u32 %2, vcc, %10, %18, vcc\n\tv_addc_co_u32 %3, vcc, %11, %19, vcc\n\t"
+        "v_addc_co_u32 %4, vcc, %12, %20, vcc\n\tv_addc_co_u32 %5, vcc, %13, %21, vcc\n\t"
+        "v_addc_co_u32 %6, vcc, %14, %22, vcc\n\tv_addc_co_u32 %7, vcc, %15, %23, vcc"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7])
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(b[0]),
+          "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]) : "vcc");
+  }
+#pragma unroll
+  for (int k = 0; k < W; ++k) t[k] = (static_cast<unsigned long long>(d[2 * k + 1]) << 32) | d[2 * k];
+}
+
+// LCS length of the wave's pattern (masks in pm, K words per symbol of which the first W are live:
+// W = ceil(la / 64), wave-uniform) and the lane's text (first nchars code units, the wave's longest
+// text; shorter texts are padded with the all-zero-mask symbol).
+//
+// EARLY: `lb` is the lane's text length and `need` the smallest LCS that still matters to it.  Every
+// 8 code units the wave checks LCS-so-far + code units still to come >= need; when no lane can reach
+// its `need` the scan stops and a value below every lane's `need` is returned (exact: one text code
+// unit adds at most one to the LCS).
+template <int K, int W, bool EARLY>
+__device__ __forceinline__ int wide_lcs_words(const unsigned long long* pm, const uint32_t* text, int nchars,
+                                              int lane, int lb, int need) {
+  unsigned long long v[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) v[k] = ~0ull;
+  const int nw = (nchars + 3) >> 2;
+  for (int w = 0; w < nw; ++w) {
     const uint32_t word = text[w * kWave + lane];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const unsigned c = (word >> (8 * b)) & 0xffu;
       const unsigned long long* e = pm + c * K;
-      unsigned long long carry = 0;
+      unsigned long long u[W], t[W];
 #pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const unsigned long long u = v[k] & e[k];
-        const unsigned long long t = __builtin_addcll(v[k], u, carry, &carry);
-        v[k] = t | (v[k] ^ u);
-      }
+      for (int k = 0; k < W; ++k) u[k] = v[k] & e[k];
+      add_chain<W>(v, u, t);
+#pragma unroll
+      for (int k = 0; k < W; ++k) v[k] = t[k] | (v[k] ^ u[k]);
+    }
+    if (EARLY && (w & 1)) {
+      int ones = 0;
+#pragma unroll
+      for (int k = 0; k < W; ++k) ones += __popcll(v[k]);
+      const int reach = kWave * W - ones + max(0, lb - 4 * (w + 1));
+      if (!__any(reach >= need)) return -1;
     }
   }
   int ones = 0;
 #pragma unroll
-  for (int k = 0; k < K; ++k) ones += __popcll(v[k]);
-  return kWave * K - ones;
+  for (int k = 0; k < W; ++k) ones += __popcll(v[k]);
+  return kWave * W - ones;
+}
+
+template <int K, bool EARLY = false>
+__device__ __forceinline__ int wide_lcs(const unsigned long long* pm, const uint32_t* text, int nchars, int lane,
+                                        int la, int lb = 0, int need = 0) {
+  const int words = (la + kWave - 1) >> 6;  // wave-uniform
+  if (words <= 1) return wide_lcs_words<K, 1, EARLY>(pm, text, nchars, lane, lb, need);
+  if (K >= 2 && words == 2) return wide_lcs_words<K, (K >= 2 ? 2 : 1), EARLY>(pm, text, nchars, lane, lb, need);
+  if (K >= 4 && words == 3) return wide_lcs_words<K, (K >= 4 ? 3 : 1), EARLY>(pm, text, nchars, lane, lb, need);
+  return wide_lcs_words<K, K, EARLY>(pm, text, nchars, lane, lb, need);
 }
 
 }  // namespace nsm
