@@ -177,6 +177,35 @@ def test_indel_raw_long_strings(dev, hi, prune):
         _same_hits(got, want)
 
 
+def test_indel_raw_term_like_strings(dev):
+    """Word-structured text with a skewed letter distribution (what real Term strings look like): the
+    histogram bound is weak there, so the in-scan early exit of the multi-word LCS decides most pairs."""
+    from napkon_string_matching_amd import grid, tables
+    from oracle import native
+
+    rng = random.Random(77)
+    letters = "eeeeeennnniiisssrrraaatttddhhuullccggmmoobbwwffkkzzvvppjyxq"
+    words = ["".join(rng.choice(letters) for _ in range(rng.randint(3, 12))) for _ in range(400)]
+    text = lambda lo, hi: " ".join(rng.choice(words[: rng.choice([20, 400])]) for _ in range(rng.randint(lo, hi)))[:256].strip()
+    left = [text(2, 30) for _ in range(300)]
+    right = [text(2, 30) for _ in range(450)]
+    for k in range(0, 450, 9):  # near-duplicates: one word replaced
+        src = left[rng.randrange(300)].split(" ")
+        src[rng.randrange(len(src))] = rng.choice(words)
+        right[k] = " ".join(src)[:256].strip()
+    lt, rt = tables.encode_strings(left, right, dev)
+    assert lt.stride == 256
+    cp = lambda ss: native.csr([[ord(c) for c in s] for s in ss])
+    base = native.indel_raw(cp(left), cp(right), 0.55, cap=1 << 18)
+    for thr in (0.55, 0.8, 0.95):
+        want = [h for h in base if h[0] >= thr]  # the oracle's list is ordered by score already
+        assert len(want) > 10
+        for prune in (True, False):
+            got = grid.indel_raw_grid(lt, rt, thr, prune=prune)
+            _same_hits(got, want, FUZZY_TOL)
+            _same_hits(got, want)
+
+
 def _nested_item(rng, vocab, max_levels, max_new, allow_empty_levels=False):
     base, out = [], []
     for _ in range(rng.randint(1, max_levels)):
