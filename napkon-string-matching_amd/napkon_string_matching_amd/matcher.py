@@ -67,6 +67,12 @@ class Matcher:
             )
 
     def match_questionnaires(self, prefix: str = None, *args, **kwargs) -> None:
+        from .types.comparable_data import ComparableData
+
+        with ComparableData.item_memo():  # every cohort takes part in several grids
+            self._match_questionnaires(prefix, **kwargs)
+
+    def _match_questionnaires(self, prefix: str = None, **kwargs) -> None:
         done = set()
         for entry_a, entry_b in product(self.questionnaires.items(), self.questionnaires.items()):
             (name_first, data_first), (name_second, data_second) = sorted(

@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import json
 import logging
+from contextlib import contextmanager
 from hashlib import md5
 from pathlib import Path
 from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple
@@ -91,11 +92,12 @@ class Tokenizer:
             return [self(items[-k:]) for k in range(1, len(items) + 1)]
         out: List[List[str]] = []
         acc: set = set()
+        stop = self.stop_words
         for entry in reversed(items):
             parts = entry if isinstance(entry, list) else [entry]
             for part in parts:
                 for w in part.split():
-                    if w.casefold() not in self.stop_words and w not in PREPARE_REMOVE_SYMBOLS:
+                    if w not in PREPARE_REMOVE_SYMBOLS and (not stop or w.casefold() not in stop):
                         acc.add(w)
             out.append(sorted(acc, key=str.casefold))
         return out
@@ -182,6 +184,36 @@ class ComparableData:
     __column_mapping__: Dict[str, str] = {}
     __category_column__ = "Category"
     tokenizer: Tokenizer = Tokenizer()
+    _item_memo: Optional[Dict[int, tuple]] = None  # see item_memo()
+
+    @classmethod
+    @contextmanager
+    def item_memo(cls):
+        """Per-ITEM results (levels, fuzzy operands) are remembered by the identity of the cell object
+        while the context is open: with k cohorts every item takes part in k - 1 grids
+        (Matcher.match_questionnaires), and dropna / rename hand the same cell objects on.  The cells
+        must not be modified in place inside the context."""
+        outer = ComparableData._item_memo
+        ComparableData._item_memo = {} if outer is None else outer
+        try:
+            yield
+        finally:
+            ComparableData._item_memo = outer
+
+    @staticmethod
+    def _memoised(tag, values, func) -> list:
+        memo = ComparableData._item_memo
+        if memo is None:
+            return [func(v) for v in values]
+        out = []
+        for v in values:
+            key = (tag, id(v))
+            got = memo.get(key)
+            if got is None or got[0] is not v:  # the memo keeps `v` alive, so its id cannot be reused
+                got = (v, func(v))
+                memo[key] = got
+            out.append(got[1])
+        return out
 
     def __init__(self, data=None) -> None:
         if isinstance(data, ComparableData):
@@ -366,8 +398,8 @@ class ComparableData:
         lp, rp = left_name.title(), right_name.title()
         n_l, n_r = len(lf), len(rf)
 
-        levels_l = [self.gen_comp_value(item) for item in lf[compare_column]]
-        levels_r = [self.gen_comp_value(item) for item in rf[compare_column]]
+        levels_l = self._memoised(("levels", id(self.tokenizer)), lf[compare_column], self.gen_comp_value)
+        levels_r = self._memoised(("levels", id(self.tokenizer)), rf[compare_column], self.gen_comp_value)
         argument_l = [":".join(flatten_list(item)) for item in lf[TERM]]
         argument_r = [":".join(flatten_list(item)) for item in rf[TERM]]
 
@@ -572,6 +604,7 @@ def _levels_grid(plugin, levels_l, levels_r, threshold, cat_l, cat_r, cat_mode=_
         if len(vocab) >= 1 << 25:
             raise NotImplementedError("vocabulary of 2^25 or more distinct tokens")
         return grid.jaccard_levels_grid(lt, rt, threshold, category_mode=cat_mode)
-    prep = lambda items: [[score_functions.fuzzy_operand(lv) for lv in it] for it in items]
+    prep = lambda items: ComparableData._memoised(
+        "fuzzy", items, lambda it: [score_functions.fuzzy_operand(lv) for lv in it])
     li, ls, ri, rs = tables.encode_level_strings(prep(levels_l), prep(levels_r), dev, cat_l, cat_r, cat_mode)
     return grid.indel_levels_grid(li, ls, ri, rs, threshold, category_mode=cat_mode)
