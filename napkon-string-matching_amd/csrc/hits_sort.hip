@@ -10,8 +10,11 @@
 //   * up to 8192 live records: rank sort -- each record counts its predecessors in one pass over
 //     LDS-staged tiles and is scattered to scratch[rank]; no inter-block dependency (O(n^2): 52 k
 //     records took 7 ms, hence the limit);
-//   * more: bitonic network in global memory, "flip" form (all comparators point the same way),
-//     which needs no padding to a power of two; passes beyond the live count exit immediately.
+//   * more: bitonic network, "flip" form (all comparators point the same way), which needs no
+//     padding to a power of two.  Every comparator pass whose partner distance is below 2048 stays
+//     inside an aligned 2048-record tile, so those passes run fused in LDS (one launch sorts all
+//     tiles, one launch finishes each larger merge); only the passes with distance >= 2048 are
+//     separate launches over global memory.  Passes beyond the live count exit immediately.
 #include "nsm_common.hpp"
 
 namespace nsm {
@@ -147,6 +150,58 @@ __global__ __launch_bounds__(kBlock) void bitonic_pass_kernel(nsm_hit* __restric
   }
 }
 
+constexpr int kTile = 2048;
+
+__device__ __forceinline__ void tile_pass(nsm_hit* tile, unsigned long long base, unsigned long long n, int k, int j) {
+  // comparators of one pass inside the tile: kTile / 2 of them, 4 per thread
+  for (int t = threadIdx.x; t < kTile / 2; t += kBlock) {
+    int lo, hi;
+    if (j == 0) {  // flip: partner = idx ^ (k - 1) inside the aligned k-block
+      const int half = k >> 1;
+      const int blk = t / half, off = t % half;
+      lo = blk * k + off;
+      hi = blk * k + (k - 1 - off);
+    } else {
+      lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+      hi = lo | j;
+    }
+    if (base + hi < n) {
+      const nsm_hit a = tile[lo];
+      const nsm_hit b = tile[hi];
+      if (hit_before(b, a)) {
+        tile[lo] = b;
+        tile[hi] = a;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// merge == 0: sort every tile (all merges up to kTile).  merge > kTile: the passes j = kTile/2 .. 1
+// that finish the merge of size `merge`.
+__global__ __launch_bounds__(kBlock) void bitonic_tile_kernel(nsm_hit* __restrict__ hits,
+                                                              unsigned long long capacity,
+                                                              const unsigned long long* __restrict__ count,
+                                                              unsigned long long merge) {
+  __shared__ nsm_hit tile[kTile];
+  const unsigned long long n = live_count(count, capacity);
+  if (n <= kRankSortMax) return;
+  if (merge && (merge >> 1) >= n) return;
+  const unsigned long long base = static_cast<unsigned long long>(blockIdx.x) * kTile;
+  if (base >= n) return;
+  const int m = static_cast<int>(n - base < kTile ? n - base : kTile);
+  for (int t = threadIdx.x; t < m; t += kBlock) tile[t] = hits[base + t];
+  __syncthreads();
+  if (merge == 0) {
+    for (int k = 2; k <= kTile; k <<= 1) {
+      tile_pass(tile, base, n, k, 0);
+      for (int j = k >> 2; j > 0; j >>= 1) tile_pass(tile, base, n, k, j);
+    }
+  } else {
+    for (int j = kTile >> 1; j > 0; j >>= 1) tile_pass(tile, base, n, 0, j);
+  }
+  for (int t = threadIdx.x; t < m; t += kBlock) hits[base + t] = tile[t];
+}
 
 }  // namespace nsm
 
@@ -174,10 +229,18 @@ extern "C" int nsm_sort_hits(nsm_hit* hits, nsm_hit* scratch, uint64_t capacity,
   if (capacity <= kRankSortMax) return hip_status(hipGetLastError(), "nsm_sort_hits (rank sort)");
   unsigned long long blocks64 = (capacity + kBlock - 1) / kBlock;
   const unsigned blocks = static_cast<unsigned>(blocks64 < 8192 ? blocks64 : 8192);
-  for (unsigned long long k = 2; (k >> 1) < capacity; k <<= 1) {
+  unsigned long long tiles64 = (capacity + kTile - 1) / kTile;
+  if (tiles64 > 0x7fffffffull) {
+    set_error("nsm_sort_hits: capacity too large");
+    return NSM_E_UNSUPPORTED;
+  }
+  const unsigned tiles = static_cast<unsigned>(tiles64);
+  hipLaunchKernelGGL(bitonic_tile_kernel, dim3(tiles), dim3(kBlock), 0, s, hits, capacity, hit_count, 0ull);
+  for (unsigned long long k = 2ull * kTile; (k >> 1) < capacity; k <<= 1) {
     hipLaunchKernelGGL(bitonic_pass_kernel, dim3(blocks), dim3(kBlock), 0, s, hits, capacity, hit_count, k, 0ull);
-    for (unsigned long long j = k >> 2; j > 0; j >>= 1)
+    for (unsigned long long j = k >> 2; j >= static_cast<unsigned long long>(kTile); j >>= 1)
       hipLaunchKernelGGL(bitonic_pass_kernel, dim3(blocks), dim3(kBlock), 0, s, hits, capacity, hit_count, k, j);
+    hipLaunchKernelGGL(bitonic_tile_kernel, dim3(tiles), dim3(kBlock), 0, s, hits, capacity, hit_count, k);
   }
   return hip_status(hipGetLastError(), "nsm_sort_hits (bitonic)");
 }

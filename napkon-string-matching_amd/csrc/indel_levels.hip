@@ -33,6 +33,27 @@ __device__ __forceinline__ double indel_score_dev(int la, int lb, int lcs) {
   return (norm_sim * 100.0) / 100.0;
 }
 
+// One-word strings (la, lb <= 64): every ratio the kernel can produce, evaluated by the compiler with
+// the same IEEE double operations (two divisions per step are ~25 double-rate VALU instructions; the
+// lookup is one cached load).  Index (la + lb) * 65 + lcs.
+struct RatioTable {
+  double v[129 * 65];
+  constexpr RatioTable() : v() {
+    for (int s = 0; s <= 128; ++s)
+      for (int lcs = 0; lcs <= 64; ++lcs) {
+        double r = 0.0;
+        if (s > 0 && 2 * lcs <= s) {
+          const double maximum = static_cast<double>(s);
+          const double dist = static_cast<double>(s - 2 * lcs);
+          const double norm_sim = 1.0 - dist / maximum;
+          r = (norm_sim * 100.0) / 100.0;
+        }
+        v[s * 65 + lcs] = r;
+      }
+  }
+};
+__device__ const RatioTable g_ratio64{};
+
 __device__ __forceinline__ int wave_max(int v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, kWave));
@@ -186,7 +207,12 @@ __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
         lcs = wide_lcs<K>(pm, wtext, nchars, lane, la);
       }
       factor *= 0.5;
-      if (active) score += indel_score_dev(la, lb, lcs) * factor;
+      if (active) {
+        double ratio;
+        if constexpr (K == 1) ratio = (la == 0 || lb == 0) ? 0.0 : g_ratio64.v[(la + lb) * 65 + lcs];
+        else ratio = indel_score_dev(la, lb, lcs);
+        score += ratio * factor;
+      }
       // exact early exit: the steps still to come add at most factor - 2^-steps < factor (ratios are
       // <= 1); when no lane can reach the threshold any more the rest of the row is skipped.  The
       // 1e-9 keeps the test safe under the rounding of the double sum.

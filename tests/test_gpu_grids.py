@@ -317,7 +317,8 @@ def test_sort_hits_large(dev):
 
     from napkon_string_matching_amd import grid
 
-    for n, cap in ((1000, 1 << 10), (5000, 1 << 13), (200_000, 1 << 18), (300_001, 300_001)):
+    for n, cap in ((1000, 1 << 10), (5000, 1 << 13), (8193, 1 << 14), (10_000, 1 << 20), (70_001, 70_001),
+                   (200_000, 1 << 18), (300_001, 300_001)):
         rng = np.random.default_rng(n)
         score = rng.integers(0, 50, n).astype(np.float64) / 49.0
         i = rng.integers(0, 1000, n).astype(np.int32)
