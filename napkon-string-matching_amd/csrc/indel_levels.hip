@@ -57,7 +57,7 @@ __device__ const RatioTable g_ratio64{};
 __device__ __forceinline__ int wave_max(int v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, kWave));
-  return v;
+  return __builtin_amdgcn_readfirstlane(v);  // a scalar: loops and branches on it stay on the SALU
 }
 
 __device__ __forceinline__ unsigned long long lev_add64(unsigned long long a, unsigned long long b) {

@@ -69,7 +69,7 @@ __device__ __forceinline__ unsigned long long lev_wave_or64(unsigned long long v
 __device__ __forceinline__ int lev_wave_max(int v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, kWave));
-  return v;
+  return __builtin_amdgcn_readfirstlane(v);
 }
 
 template <int W, int NB>
