@@ -54,26 +54,10 @@ struct RatioTable {
 };
 __device__ const RatioTable g_ratio64{};
 
-__device__ __forceinline__ int wave_max(int v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, kWave));
-  return __builtin_amdgcn_readfirstlane(v);  // a scalar: loops and branches on it stay on the SALU
-}
-
 __device__ __forceinline__ unsigned long long lev_add64(unsigned long long a, unsigned long long b) {
   unsigned long long d;  // one VALU op (see indel_raw.hip)
   asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(d) : "v"(a), "v"(b));
   return d;
-}
-
-__device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
-  uint32_t lo = static_cast<uint32_t>(v), hi = static_cast<uint32_t>(v >> 32);
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    lo |= __shfl_xor(lo, off, kWave);
-    hi |= __shfl_xor(hi, off, kWave);
-  }
-  return (static_cast<unsigned long long>(hi) << 32) | lo;
 }
 
 template <int K>
@@ -103,7 +87,7 @@ __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
   const int i0 = blockIdx.y * p.rows_per_chunk;
   const int i1 = min(p.n_left, i0 + p.rows_per_chunk);
   if (partitioned) {  // most (tile, chunk) combinations hold no row of the tile's categories: leave early
-    unsigned long long cats = wave_or64(valid ? (1ull << myseg) : 0ull);
+    unsigned long long cats = wave_or_u64(valid ? (1ull << myseg) : 0ull);
     bool work = false;
     while (cats) {
       const int c = __builtin_ctzll(cats);
@@ -117,7 +101,7 @@ __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
   const int rrow0 = rfirst[jc];
   const int jorig = rorig[jc];
   const uint64_t catr = (p.cat_mode != NSM_CAT_NONE) ? rcat[jc] : 0ull;
-  const int lr_max = wave_max(valid ? lr : 0);
+  const int lr_max = wave_max_i32(valid ? lr : 0);
   unsigned long long* pm = s_pm + wave * p.pm_stride * K;
   uint32_t* wtext = reinterpret_cast<uint32_t*>(s_pm + waves * p.pm_stride * K) + wave * 16 * K * kWave;
 
@@ -167,7 +151,7 @@ __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
           lb = rlen[rrow];
         }
       }
-      const int nchars = wave_max(active ? lb : 0);
+      const int nchars = wave_max_i32(active ? lb : 0);
       int lcs;
       if constexpr (K == 1) {
         const int nwords = (nchars + 3) >> 2;
@@ -227,7 +211,7 @@ __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
   if (partitioned) {
     // both sides are grouped by category: visit the left rows of the categories this wave's lanes
     // stand for, and report a pair in its lowest common category only
-    unsigned long long cats = wave_or64(valid ? (1ull << myseg) : 0ull);
+    unsigned long long cats = wave_or_u64(valid ? (1ull << myseg) : 0ull);
     while (cats) {
       const int c = __builtin_ctzll(cats);
       cats &= cats - 1;

@@ -56,22 +56,6 @@ __device__ __forceinline__ uint32_t lev_min3u(uint32_t a, uint32_t b, uint32_t c
   return d;
 }
 
-__device__ __forceinline__ unsigned long long lev_wave_or64(unsigned long long v) {
-  uint32_t lo = static_cast<uint32_t>(v), hi = static_cast<uint32_t>(v >> 32);
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    lo |= __shfl_xor(lo, off, kWave);
-    hi |= __shfl_xor(hi, off, kWave);
-  }
-  return (static_cast<unsigned long long>(hi) << 32) | lo;
-}
-
-__device__ __forceinline__ int lev_wave_max(int v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, kWave));
-  return __builtin_amdgcn_readfirstlane(v);
-}
-
 template <int W, int NB>
 __device__ __forceinline__ void levels_wave(
     const int32_t* __restrict__ lids, const int32_t* __restrict__ lcnt, const uint64_t* __restrict__ lsig,
@@ -99,7 +83,7 @@ __device__ __forceinline__ void levels_wave(
       l[4 * q + 3] = v.w << 6;
     }
     const int nl = lcnt[ii];
-    const int nl_max = lev_wave_max(active ? nl : 0);
+    const int nl_max = wave_max_i32(active ? nl : 0);
     uint32_t posw[W / 4];
 #pragma unroll
     for (int q = 0; q < W / 4; ++q) {
@@ -154,7 +138,7 @@ __device__ __forceinline__ void levels_wave(
   };
 
   auto flush = [&]() {
-    const int deepest = lev_wave_max(qn);
+    const int deepest = wave_max_i32(qn);
     for (int k = 0; k < deepest; ++k) {
       const int idx = (k < qn) ? i0 + static_cast<int>(queue[k * kWave + lane]) : -1;
       verify(idx);
@@ -219,7 +203,7 @@ __device__ __forceinline__ void levels_wave(
   };
 
   if (partitioned) {
-    unsigned long long cats = lev_wave_or64(valid ? (1ull << myseg) : 0ull);
+    unsigned long long cats = wave_or_u64(valid ? (1ull << myseg) : 0ull);
     while (cats) {
       const int c = __builtin_ctzll(cats);
       cats &= cats - 1;
@@ -269,7 +253,7 @@ __global__ __launch_bounds__(kBlock) void jaccard_levels_kernel(
   const int i0 = blockIdx.y * p.rows_per_chunk;
   const int i1 = min(p.n_left, i0 + p.rows_per_chunk);
   if (partitioned) {  // most (tile, chunk) combinations hold no row of the tile's categories: leave early
-    unsigned long long cats = lev_wave_or64(valid ? (1ull << myseg) : 0ull);
+    unsigned long long cats = wave_or_u64(valid ? (1ull << myseg) : 0ull);
     bool work = false;
     while (cats) {
       const int c = __builtin_ctzll(cats);
@@ -296,7 +280,7 @@ __global__ __launch_bounds__(kBlock) void jaccard_levels_kernel(
   const int jorig = rorig[jc];
   const uint8_t* rplen_row = rplen + static_cast<size_t>(jc) * p.lev_stride_r;
   const int pr1 = rplen_row[1];
-  const int nbmax = lev_wave_max(nrj);  // (with a category partition lane 0 is not the largest)
+  const int nbmax = wave_max_i32(nrj);  // (with a category partition lane 0 is not the largest)
 
   constexpr int NBS = W / 8;
   const int cls = (nbmax + NBS - 1) / NBS;

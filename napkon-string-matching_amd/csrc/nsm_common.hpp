@@ -31,6 +31,37 @@ __device__ __forceinline__ void emit_hit(nsm_hit* __restrict__ hits, unsigned lo
 
 __device__ __forceinline__ int wave_first(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// Wave-wide max / or of a per-lane value, returned as a SCALAR (loops and branches on it stay on the
+// SALU).  Four DPP steps leave every 16-lane row with its own result, four v_readlane + SALU ops
+// combine the rows -- no LDS traffic, unlike the ds_bpermute chain __shfl_xor expands to.  Must be
+// called with all 64 lanes enabled.
+template <typename Op>
+__device__ __forceinline__ uint32_t wave_reduce_u32(uint32_t v, Op op) {
+  const int x = static_cast<int>(v);
+  int r = x;
+  r = static_cast<int>(op(static_cast<uint32_t>(r), static_cast<uint32_t>(__builtin_amdgcn_update_dpp(r, r, 0xB1, 0xf, 0xf, false))));   // quad_perm [1,0,3,2]
+  r = static_cast<int>(op(static_cast<uint32_t>(r), static_cast<uint32_t>(__builtin_amdgcn_update_dpp(r, r, 0x4E, 0xf, 0xf, false))));   // quad_perm [2,3,0,1]
+  r = static_cast<int>(op(static_cast<uint32_t>(r), static_cast<uint32_t>(__builtin_amdgcn_update_dpp(r, r, 0x141, 0xf, 0xf, false))));  // row_half_mirror
+  r = static_cast<int>(op(static_cast<uint32_t>(r), static_cast<uint32_t>(__builtin_amdgcn_update_dpp(r, r, 0x140, 0xf, 0xf, false))));  // row_mirror
+  const uint32_t a = static_cast<uint32_t>(__builtin_amdgcn_readlane(r, 0));
+  const uint32_t b = static_cast<uint32_t>(__builtin_amdgcn_readlane(r, 16));
+  const uint32_t c = static_cast<uint32_t>(__builtin_amdgcn_readlane(r, 32));
+  const uint32_t d = static_cast<uint32_t>(__builtin_amdgcn_readlane(r, 48));
+  return op(op(a, b), op(c, d));
+}
+
+// values must be >= 0
+__device__ __forceinline__ int wave_max_i32(int v) {
+  return static_cast<int>(wave_reduce_u32(static_cast<uint32_t>(v), [](uint32_t x, uint32_t y) { return x > y ? x : y; }));
+}
+
+__device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) {
+  auto bit_or = [](uint32_t x, uint32_t y) { return x | y; };
+  const uint32_t lo = wave_reduce_u32(static_cast<uint32_t>(v), bit_or);
+  const uint32_t hi = wave_reduce_u32(static_cast<uint32_t>(v >> 32), bit_or);
+  return (static_cast<unsigned long long>(hi) << 32) | lo;
+}
+
 __device__ __forceinline__ bool category_match(uint64_t cl, uint64_t cr, int mode) {
   // types/comparable_data.py:467-476; the predicate kind was chosen by the host from row 0.
   const bool inter = (cl & cr) != 0;
