@@ -68,7 +68,10 @@ typedef struct nsm_hit {
  *                                  set on both sides together with NSM_CAT_INTERSECT; rows sorted by seg,
  *                                  then by cnt descending
  *   filt  device uint32[n][8]      filter record of the row: {sig lo, sig hi, cat lo, cat hi,
- *                                  plen[min(1,L-1)] | cnt << 8 | nlev << 16, 0, 0, 0} (one s_load per 2 rows)
+ *                                  plen[min(1,L-1)] | cnt << 8 | nlev << 16, sig1 lo, sig1 hi, 0} where sig1
+ *                                  is the signature word (same layout as sig) of the row's first
+ *                                  plen[min(1,L-1)] ids, i.e. of the set every step of compare_terms contains
+ *                                  (one s_load per 2 rows)
  */
 typedef struct nsm_set_table {
   const int32_t* ids;

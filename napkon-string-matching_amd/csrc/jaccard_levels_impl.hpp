@@ -11,9 +11,12 @@
 //
 // Structure: FILTER all pairs cheaply, VERIFY the survivors exactly -- per lane, not per wave.
 //   * lane = right item (ids in registers); the left rows of the chunk stream by, wave-uniform;
-//   * filter (per row, ~13 VALU ops): category predicate, and the necessary condition
-//         score <= |A n B| / |B_1|  and  |A n B| <= popcount(hashbits(A) & hashbits(B)) + cA
-//     (every level from step 1 on contains level 1; signature words as in the RAW kernel).  A lane
+//   * filter (per row, ~19 VALU ops): category predicate, and the necessary condition
+//         score <= ( |A_1 n B_1| + min(|A n B|, m) ) / (2 m),   m = max(|A_1|, |B_1|) >= own |B_1|
+//     (step 1 weighs 1/2 and compares the step-1 sets; every later step contains them, so its Jaccard
+//     is at most min(1, |A n B| / m), and the later weights sum to less than 1/2), with
+//         |X n Y| <= popcount(hashbits(X) & hashbits(Y)) + collisions(X)
+//     for the whole rows and for the step-1 sets (signature words as in the RAW kernel).  A lane
 //     that passes appends the row to ITS OWN candidate queue in LDS;
 //   * verify: when some queue fills up (and at the end) the wave walks the queue slots; in slot k every
 //     lane gathers ITS k-th candidate row from HBM/L2 and scores the pair exactly:
@@ -43,8 +46,6 @@ struct JacLevScalars {
   int32_t emit_all;      // threshold <= 0: every pair that passes the category predicate is a hit
   double threshold;
   unsigned long long cap;
-  unsigned long long bneed;  // 16 x 4 bits: least |A n B| that can reach the threshold when
-                             // max(|A_1|, |B_1|) = m (m clamped to 15: a smaller m is a weaker, valid test)
 };
 
 template <int W>
@@ -62,11 +63,13 @@ __device__ __forceinline__ void levels_wave(
     const int32_t* __restrict__ lorig, const int32_t* __restrict__ lnlev, const uint8_t* __restrict__ lplen,
     const uint64_t* __restrict__ lcat, const uint8_t* __restrict__ rplen_row, nsm_hit* __restrict__ hits,
     unsigned long long* __restrict__ count, const JacLevScalars<W>& p, const uint32_t (&r)[W], uint64_t sr,
-    uint64_t catr, int lr, int pr1, int jorig, bool valid, int i0, int i1, uint16_t* queue,
+    uint64_t sr1, uint64_t catr, int lr, int pr1, int jorig, bool valid, int i0, int i1, uint16_t* queue,
     const double* quot, const uint32_t* __restrict__ lfilt, const int32_t* __restrict__ lsegstart, bool partitioned,
     int myseg, int lane) {
   int qn = 0;  // candidates queued by this lane
-  const int bneed_r = static_cast<int>((p.bneed >> (4 * min(pr1, 15))) & 15ull);
+  // least |A_1 n B_1| + min(|A n B|, |B_1|) that can reach the threshold; the factor (1 - 1e-9) keeps
+  // the test necessary under the rounding of the double accumulation
+  const int bneed_r = static_cast<int>(ceil(2.0 * p.threshold * static_cast<double>(pr1) * (1.0 - 1e-9)));
 
   // ---- exact score of (left row idx, this lane's right item); idx < 0: the lane idles
   auto verify = [&](int idx) {
@@ -158,6 +161,7 @@ __device__ __forceinline__ void levels_wave(
   const int need_r = valid ? (p.emit_all ? -1 : bneed_r) : 1 << 20;  // invalid lanes never pass
   const uint32_t catr_lo = static_cast<uint32_t>(catr), catr_hi = static_cast<uint32_t>(catr >> 32);
   const uint32_t sr_lo = static_cast<uint32_t>(sr), sr_hi = static_cast<uint32_t>(sr >> 32);
+  const uint32_t sr1_lo = static_cast<uint32_t>(sr1), sr1_hi = static_cast<uint32_t>(sr1 >> 32);
   uint32_t rowv = 0;                                  // row offset inside the chunk, in a VGPR
   const uint32_t qbase = static_cast<uint32_t>(lane * 2);  // byte offset of the lane's queue column
 
@@ -165,10 +169,14 @@ __device__ __forceinline__ void levels_wave(
   // and a pair is dropped when the two items also share a LOWER category (it is reported there)
   bool seg_ok = true;
   uint32_t lower_lo = 0, lower_hi = 0;  // catr restricted to the categories below c
-  auto filter_row = [&](uint32_t sig_lo, uint32_t sig_hi, uint32_t cat_lo, uint32_t cat_hi) {
-    int bound;
+  auto filter_row = [&](uint32_t sig_lo, uint32_t sig_hi, uint32_t cat_lo, uint32_t cat_hi, uint32_t sig1_lo,
+                        uint32_t sig1_hi) {
+    int bound, bound1;
     asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(bound) : "v"(sig_lo & sr_lo), "s"(sig_hi >> 26));
     asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(bound) : "v"(sig_hi & sr_hi), "v"(bound));
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(bound1) : "v"(sig1_lo & sr1_lo), "s"(sig1_hi >> 26));
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(bound1) : "v"(sig1_hi & sr1_hi), "v"(bound1));
+    bound = min(bound, pr1) + bound1;
     bool pass = bound >= need_r;
     if (partitioned) {
       pass = pass && seg_ok && (((cat_lo & lower_lo) | (cat_hi & lower_hi)) == 0u);
@@ -193,11 +201,11 @@ __device__ __forceinline__ void levels_wave(
 #pragma unroll
       for (int q = 0; q < 8 * BATCH; ++q) f[q] = fp[q];
 #pragma unroll
-      for (int q = 0; q < BATCH; ++q) filter_row(f[8 * q + 0], f[8 * q + 1], f[8 * q + 2], f[8 * q + 3]);
+      for (int q = 0; q < BATCH; ++q) filter_row(f[8 * q + 0], f[8 * q + 1], f[8 * q + 2], f[8 * q + 3], f[8 * q + 5], f[8 * q + 6]);
       if (__any(qn > kQueueSlots - BATCH - 1)) flush();
     }
     for (; i < b; ++i, fp += 8) {
-      filter_row(fp[0], fp[1], fp[2], fp[3]);
+      filter_row(fp[0], fp[1], fp[2], fp[3], fp[5], fp[6]);
       if (__any(qn > kQueueSlots - BATCH - 1)) flush();
     }
   };
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(kBlock) void jaccard_levels_kernel(
     const uint64_t* __restrict__ lcat, const int32_t* __restrict__ rids, const int32_t* __restrict__ rcnt,
     const uint64_t* __restrict__ rsig, const int32_t* __restrict__ rorig, const int32_t* __restrict__ rnlev,
     const uint8_t* __restrict__ rplen, const uint64_t* __restrict__ rcat, const uint32_t* __restrict__ lfilt,
-    const int32_t* __restrict__ lsegstart, const int32_t* __restrict__ rseg, nsm_hit* __restrict__ hits, unsigned long long* __restrict__ count, const JacLevScalars<W> p) {
+    const uint32_t* __restrict__ rfilt, const int32_t* __restrict__ lsegstart, const int32_t* __restrict__ rseg, nsm_hit* __restrict__ hits, unsigned long long* __restrict__ count, const JacLevScalars<W> p) {
   __shared__ uint16_t s_queue[kWavesPerBlock][kQueueSlots * kWave];
   __shared__ double s_quot[kQuotTable<W> ? (W + 1) * (2 * W + 1) : 1];
   if constexpr (kQuotTable<W>) {
@@ -275,6 +283,8 @@ __global__ __launch_bounds__(kBlock) void jaccard_levels_kernel(
   }
   const int nrj = valid ? rcnt[jc] : 0;
   const uint64_t sr = valid ? (rsig[jc] & ((1ull << 58) - 1)) : 0ull;  // hash bits only
+  const uint32_t* rf = rfilt + static_cast<size_t>(jc) * 8;
+  const uint64_t sr1 = valid ? (((static_cast<uint64_t>(rf[6]) << 32) | rf[5]) & ((1ull << 58) - 1)) : 0ull;
   const uint64_t catr = (p.cat_mode != NSM_CAT_NONE) ? rcat[jc] : 0ull;
   const int lr = rnlev[jc];
   const int jorig = rorig[jc];
@@ -286,7 +296,7 @@ __global__ __launch_bounds__(kBlock) void jaccard_levels_kernel(
   const int cls = (nbmax + NBS - 1) / NBS;
 #define NSM_LEV_CASE(K)                                                                               \
   levels_wave<W, (K) * NBS>(lids, lcnt, lsig, lorig, lnlev, lplen, lcat, rplen_row, hits, count, p, r, sr, \
-                            catr, lr, pr1, jorig, valid, i0, i1, s_queue[wave], s_quot, lfilt, lsegstart, partitioned, myseg, lane)
+                            sr1, catr, lr, pr1, jorig, valid, i0, i1, s_queue[wave], s_quot, lfilt, lsegstart, partitioned, myseg, lane)
   switch (cls) {
     case 0:
     case 1: NSM_LEV_CASE(1); break;
@@ -324,15 +334,6 @@ int launch_levels(const nsm_set_table* l, const nsm_set_table* r, double thresho
   p.cat_mode = category_mode;
   p.threshold = threshold;
   p.emit_all = !(threshold > 0.0);  // also true for NaN: then nothing compares >= and nothing is emitted
-  // score < |A n B| / m with m = max(|A_1|, |B_1|) (every level from step 1 on contains level 1 and
-  // the weights sum to less than 1): a pair needs |A n B| >= threshold * m.  The factor (1 - 1e-9)
-  // keeps the test necessary under the rounding of the double accumulation.
-  p.bneed = 0;
-  for (int m = 0; m < 16; ++m) {
-    int need = 0;
-    while (need < 15 && static_cast<double>(need) < threshold * static_cast<double>(m) * (1.0 - 1e-9)) ++need;
-    p.bneed |= static_cast<unsigned long long>(need) << (4 * m);
-  }
   const int n_tiles = (r->n + kWave - 1) / kWave;
   p.rows_per_chunk = lev_rows_per_chunk(l->n, n_tiles);
   // with a category partition a tile only works on the chunks that overlap its categories' row
@@ -345,7 +346,7 @@ int launch_levels(const nsm_set_table* l, const nsm_set_table* r, double thresho
   }
   hipLaunchKernelGGL((jaccard_levels_kernel<W>), grid, dim3(kBlock), 0, stream, l->ids, l->cnt, l->sig, l->orig,
                      l->nlev, l->plen, l->cat, r->ids, r->cnt, r->sig, r->orig, r->nlev, r->plen, r->cat, l->filt,
-                     l->seg_start, r->seg, hits, hit_count, p);
+                     r->filt, l->seg_start, r->seg, hits, hit_count, p);
   return hip_status(hipGetLastError(), "jaccard_levels_kernel launch");
 }
 

@@ -298,8 +298,11 @@ class SetTable:
                 c = cat[perm]
                 filt[:, 2] = (c & np.uint64(0xFFFFFFFF)).astype(np.uint32)
                 filt[:, 3] = (c >> np.uint64(32)).astype(np.uint32)
-            filt[:, 4] = plen[perm][:, 1].astype(np.uint32) | (cnt_s.astype(np.uint32) << 8) | (
-                nlev[perm].astype(np.uint32) << 16)
+            plen1 = plen[perm][:, 1].astype(np.int32)  # size of the step-1 set (plen is padded with its last value)
+            filt[:, 4] = plen1.astype(np.uint32) | (cnt_s.astype(np.uint32) << 8) | (nlev[perm].astype(np.uint32) << 16)
+            sig_l1 = signatures(ids, np.minimum(plen1, cnt_s))
+            filt[:, 5] = (sig_l1 & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+            filt[:, 6] = (sig_l1 >> np.uint64(32)).astype(np.uint32)
         return cls(
             filt=None if filt is None else _dev(filt, device),
             ids=_dev(ids, device),

@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--check", type=int, default=0)
     ap.add_argument("--threshold", type=float, default=0.7)
     ap.add_argument("--vocab", type=int, default=20_000)
+    ap.add_argument("--tokens-per-entry", type=int, default=2,
+                    help="words per entry; 6 makes the level strings 40..170 code units (multi-word Indel kernels)")
     args = ap.parse_args()
 
     import numpy as np
@@ -40,15 +42,17 @@ def main():
     names = ["hap", "pop", "suep"]
     cohorts = {}
     for k, nm in enumerate(names):  # pop and suep carry 1 % near-duplicates of hap items
-        cohorts[nm] = synthetic.c5_cohort(args.rows, 11 + k, vocab=args.vocab, plant_from=cohorts.get("hap"))
+        cohorts[nm] = synthetic.c5_cohort(args.rows, 11 + k, vocab=args.vocab, plant_from=cohorts.get("hap"),
+                                          tokens_per_entry=args.tokens_per_entry)
     pairs = [("hap", "pop"), ("hap", "suep"), ("pop", "suep")]
 
+    width = tables.pick_width(4 * args.tokens_per_entry)
     t0 = time.perf_counter()
     set_tables = {}
     for nm, c in cohorts.items():
         for side in ("left", "right"):
             set_tables[nm, side] = tables.SetTable.from_nested_arrays(
-                c["ids"], c["plen"], c["nlev"], side, dev, categories=c["cat"], width=16,
+                c["ids"], c["plen"], c["nlev"], side, dev, categories=c["cat"], width=width,
                 category_mode=_lib.CAT_INTERSECT_OR_BOTH_EMPTY)
     t_sets = time.perf_counter() - t0
     t0 = time.perf_counter()
@@ -82,6 +86,7 @@ def main():
         lib.nsm_sort_hits(buf.records.data_ptr(), buf.scratch.data_ptr(), buf.capacity, buf.count.data_ptr(), stream)
 
     out = {"rows_per_cohort": args.rows, "threshold": args.threshold, "pairs_per_grid": args.rows ** 2,
+           "tokens_per_entry": args.tokens_per_entry, "string_stride": str_tables[pairs[0]][1].stride,
            "encode_seconds": {"sets": round(t_sets, 2), "level_strings": round(t_strs, 2)}}
     for label, fn in (("intersection_vs_union", run_jaccard), ("fuzzy_match", run_indel)):
         fn(*pairs[0])
@@ -109,10 +114,10 @@ def main():
             ids = lambda items: [[[vocab.setdefault(t, len(vocab)) for t in lv] for lv in it] for it in items]
             want = native.levels(False, ids(la), ids(lb), args.threshold, cohorts[a]["cat"][:m], cohorts[b]["cat"][:m], 2)
             sub_l = tables.SetTable.from_nested_arrays(cohorts[a]["ids"][:m], cohorts[a]["plen"][:m], cohorts[a]["nlev"][:m],
-                                                       "left", dev, categories=cohorts[a]["cat"][:m], width=16,
+                                                       "left", dev, categories=cohorts[a]["cat"][:m], width=width,
                                                        category_mode=mode)
             sub_r = tables.SetTable.from_nested_arrays(cohorts[b]["ids"][:m], cohorts[b]["plen"][:m], cohorts[b]["nlev"][:m],
-                                                       "right", dev, categories=cohorts[b]["cat"][:m], width=16,
+                                                       "right", dev, categories=cohorts[b]["cat"][:m], width=width,
                                                        category_mode=mode)
             got = grid.jaccard_levels_grid(sub_l, sub_r, args.threshold, category_mode=mode).as_tuples()
             assert got == want, (a, b, len(got), len(want))
