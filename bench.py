@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: pair-comparisons/sec of the all-pairs match loop on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5] [--no-cpu-baseline]
 
 N > 1 is launched by the driver as
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -13,7 +13,10 @@ replicated; per-GPU work is fixed as N grows ("weak").
 
 Workload at N = 1 is BASELINE.json configs[1] ("c2": 50k x 50k token-id sets, mean 8 ids,
 intersection_vs_union, threshold 0.5); `--workload c3` runs configs[2] (200k x 200k strings,
-fuzzy_match, threshold 0.8).
+fuzzy_match, threshold 0.8).  `--workload c4` is configs[3] (1M x 1M token-id sets, threshold 0.8, the
+1M left rows divided over the ranks: "strong"); `--workload c5` is configs[4] (three 500k-item
+cohorts, 4 levels, 32 categories, filter_categories, both score functions back to back through the
+levels-mode kernels, left rows of every cohort pair divided over the ranks: "strong").
 
 The JSON line carries, besides the driver's contract fields:
   roofline      dominant kernel; achieved = algorithmic bytes (128 B per pair) per
@@ -42,7 +45,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=("c2", "c3"), default="c2")
+    ap.add_argument("--workload", choices=("c2", "c3", "c4", "c5"), default="c2")
     ap.add_argument("--rows", type=int, default=0, help="override rows per side per GPU (debug)")
     ap.add_argument("--right-rows", type=int, default=0, help="override the right side's rows (debug)")
     ap.add_argument("--threshold", type=float, default=None, help="override the workload's threshold (debug)")
@@ -65,7 +68,14 @@ class Workload:
         self.name = name
         self.lib = _lib.load()
         self.flag_prune = _lib.FLAG_PRUNE
-        if name == "c2":
+        self.scaling = "weak"
+        if name == "c4":  # configs[3]: the C2 generator at 1M x 1M, threshold 0.8, left rows divided over the ranks
+            total = rows or 1_000_000
+            right_rows = right_rows or total
+            rows = -(-total // world)
+            threshold = 0.8 if threshold is None else threshold
+            self.scaling = "strong"
+        if name in ("c2", "c4"):
             n = rows or 50_000
             m = right_rows or rows or 50_000
             self.threshold = 0.5 if threshold is None else threshold
@@ -89,7 +99,8 @@ class Workload:
             self.launch_fn = self.lib.nsm_jaccard_raw_grid
             self.kernel = "jaccard_raw_kernel<16>"
             self.dtype = "int32"
-            self.label = f"C2: {n}x{m} token-id sets/GPU (Poisson(8) ids, W=16), intersection_vs_union RAW, threshold {self.threshold}"
+            self.label = (f"{name.upper()}: {n}x{m} token-id sets/GPU (Poisson(8) ids, W=16), intersection_vs_union RAW, "
+                          f"threshold {self.threshold}")
         else:
             n = rows or 200_000
             m = right_rows or rows or 200_000
@@ -166,7 +177,7 @@ def cpu_baseline(work, budget_pairs):
     from napkon_string_matching_amd import synthetic
     from oracle import compare as oc
 
-    if work.name == "c2":
+    if work.name in ("c2", "c4"):
         side = int(budget_pairs ** 0.5)
         left = synthetic.decode_sets(work.left_np[:side])
         right = synthetic.decode_sets(work.right_np[:side])
@@ -192,6 +203,188 @@ def cpu_baseline(work, budget_pairs):
         "seconds": round(dt, 2),
         "host_cpus": os.cpu_count(),
     }
+
+
+def run_c5(args, rank, world, device, dist):
+    """BASELINE configs[4]: three hap / pop / suep shaped cohorts, levels mode (compare_terms), categories
+    filtered, intersection_vs_union then fuzzy_match for every cohort pair.  One step = the six grids.
+    The left rows of every cohort pair are divided over the ranks (total work fixed: "strong")."""
+    import numpy as np
+    import torch
+
+    from napkon_string_matching_amd import _lib, distributed, grid, synthetic, tables
+    from napkon_string_matching_amd.compare import score_functions as sf
+
+    lib = _lib.load()
+    rows = args.rows or 500_000
+    threshold = 0.7 if args.threshold is None else args.threshold  # max(cache 0.5, score 0.7), config.yml:11-12
+    mode = _lib.CAT_INTERSECT_OR_BOTH_EMPTY
+    names = ("hap", "pop", "suep")
+    cohorts = {}
+    for k, nm in enumerate(names):  # the same on every rank (seeded); pop / suep carry 1 % near-duplicates of hap
+        cohorts[nm] = synthetic.c5_cohort(rows, 11 + k, plant_from=cohorts.get("hap"))
+    pairs = [("hap", "pop"), ("hap", "suep"), ("pop", "suep")]
+    lo, hi = distributed.shard_bounds(rows, rank, world)
+    t0 = time.perf_counter()
+    level_strings = {nm: [[sf.fuzzy_operand(lv) for lv in it] for it in synthetic.c5_level_token_lists(c)]
+                     for nm, c in cohorts.items()}
+    grids = []
+    for a, b in pairs:
+        ca, cb = cohorts[a], cohorts[b]
+        lt = tables.SetTable.from_nested_arrays(ca["ids"][lo:hi], ca["plen"][lo:hi], ca["nlev"][lo:hi], "left", device,
+                                                categories=ca["cat"][lo:hi], width=16, category_mode=mode,
+                                                orig=np.arange(lo, hi, dtype=np.int32))
+        rt = tables.SetTable.from_nested_arrays(cb["ids"], cb["plen"], cb["nlev"], "right", device,
+                                                categories=cb["cat"], width=16, category_mode=mode)
+        li, ls, ri, rs = tables.encode_level_strings(level_strings[a][lo:hi], level_strings[b], device, ca["cat"][lo:hi],
+                                                     cb["cat"], mode, left_offset=lo)
+        grids.append(("jaccard", (lt, rt), (lt.struct(), rt.struct()), lt.category_mode))
+        grids.append(("indel", (li, ls, ri, rs), (li.struct(), ls.struct(), ri.struct(), rs.struct()), li.category_mode))
+    torch.cuda.synchronize(device)
+    t_encode = time.perf_counter() - t0
+
+    capacity = max(args.capacity, 1 << 16)
+    bufs = [grid.HitBuffer(capacity, device) for _ in range(2)]
+    for b in bufs:
+        b.scratch = torch.empty_like(b.records)
+    gathered = [torch.empty((world,) + tuple(b.storage.shape), dtype=b.storage.dtype, device=device) for b in bufs]
+    pending = [None, None]
+    stream = torch.cuda.current_stream(device).cuda_stream
+    turn = [0]
+    counts = []
+
+    def launch(g, b):
+        kind, _keep, st, cat_mode = g
+        if kind == "jaccard":
+            rc = lib.nsm_jaccard_levels_grid(st[0], st[1], float(threshold), cat_mode, 1, b.records.data_ptr(), b.capacity,
+                                             b.count.data_ptr(), stream)
+        else:
+            rc = lib.nsm_indel_levels_grid(st[0], st[1], st[2], st[3], float(threshold), cat_mode, 1, b.records.data_ptr(),
+                                           b.capacity, b.count.data_ptr(), stream)
+        _lib.check(rc, kind + "_levels_grid")
+
+    def step(record=False):
+        for g in grids:
+            k = turn[0] & 1
+            turn[0] += 1
+            b = bufs[k]
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
+            b.count.zero_()
+            launch(g, b)
+            lib.nsm_sort_hits(b.records.data_ptr(), b.scratch.data_ptr(), b.capacity, b.count.data_ptr(), stream)
+            if world > 1:
+                pending[k] = gather_hits(b, gathered[k], world, device, async_op=True)
+            if record:
+                counts.append(int(b.count.item()))
+
+    def fence():
+        for k in (0, 1):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    step(record=True)
+    fence()
+    if max(counts) > capacity:
+        raise SystemExit(f"hit buffer overflow ({max(counts)} > {capacity}); raise --capacity")
+
+    # dominant kernel: indel_levels_kernel (the three fuzzy grids of a step), HIP events on the launch stream
+    def kernel_ms(kind, reps):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        b = bufs[0]
+        torch.cuda.synchronize(device)
+        ev0.record()
+        for _ in range(reps):
+            for g in grids:
+                if g[0] == kind:
+                    launch(g, b)
+        ev1.record()
+        torch.cuda.synchronize(device)
+        return ev0.elapsed_time(ev1) / reps
+
+    reps = max(2, min(args.steps, 5))
+    ms_indel, ms_jac = kernel_ms("indel", reps), kernel_ms("jaccard", reps)
+    pairs_per_step = 2 * len(pairs) * rows * rows  # both score functions over every cohort pair
+    local_pairs = len(pairs) * (hi - lo) * rows    # pairs one fuzzy pass of this rank scores
+    bytes_per_pair = 2 * 4 * 64                     # both items' level storage: 4 level strings of 64 B each
+    achieved = local_pairs * bytes_per_pair / (ms_indel * 1e-3) / 1e9
+    result = {
+        "metric": "pair-comparisons/sec (whole node), N x M all-pairs",
+        "value": pairs_per_step * args.steps / dt,
+        "unit": "pair-comparisons/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": max(1, args.warmup),
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "int32 (intersection_vs_union) + u64 (fuzzy_match), f64 scores",
+        "data": "synthetic",
+        "config": {
+            "workload": f"C5: 3 cohorts x {rows} items (4 levels, ~8 tokens, 1-2 of 32 categories), compare_terms levels mode, "
+                        f"filter_categories, intersection_vs_union then fuzzy_match, threshold {threshold}",
+            "mode": "MATCHER",
+            "threshold": threshold,
+            "pairs_per_step": pairs_per_step,
+            "hits_per_grid_this_rank": counts,
+            "sharding": f"left rows of every cohort pair block-sharded over {world} rank(s), right replicated, hits all-gathered",
+            "encode_and_h2d_seconds_once": round(t_encode, 2),
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "indel_levels_kernel<1> (3 launches per step)",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": None,
+            "kernel_ms": ms_indel,
+            "algorithmic_bytes_per_pair": bytes_per_pair,
+            "jaccard_levels_kernel_ms": ms_jac,
+        },
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import compare as oc
+        from oracle import score_functions as osf
+
+        side = 300
+        la = synthetic.c5_level_token_lists(cohorts["hap"], slice(0, side))
+        lb = synthetic.c5_level_token_lists(cohorts["pop"], slice(0, side))
+        ca, cb = cohorts["hap"]["cat"][:side], cohorts["pop"]["cat"][:side]
+        t0 = time.perf_counter()
+        kept = 0
+        for func in (osf.intersection_vs_union, osf.fuzzy_match):
+            for i in range(side):
+                for j in range(side):
+                    if (int(ca[i]) & int(cb[j])) or (not ca[i] and not cb[j]):  # categories_matching first (:213-221)
+                        kept += oc.compare_terms(la[i], lb[j], func) >= threshold
+        dt_cpu = time.perf_counter() - t0
+        result["cpu_baseline"] = {
+            "value": 2 * side * side / dt_cpu, "unit": "pair-comparisons/s", "cores": 1, "kind": "port",
+            "sample": f"{side}x{side} hap x pop corner, category predicate then compare_terms per pair, both score functions "
+                      "(Python; fuzzy_match = pure-Python LCS, NOT rapidfuzz)",
+            "seconds": round(dt_cpu, 2), "host_cpus": os.cpu_count(),
+        }
+    if rank == 0:
+        print(json.dumps(result))
 
 
 def main():
@@ -222,6 +415,13 @@ def main():
 
     from napkon_string_matching_amd import grid
 
+    if args.workload == "c4" and args.capacity == 1 << 13:
+        args.capacity = 1 << 16  # ~12k hits at 1M x 1M
+    if args.workload == "c5":
+        run_c5(args, rank, world, device, dist)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     work = Workload(args.workload, rank, world, args.rows, device, args.right_rows, args.threshold)
     # two hit buffers: the all-gather of step k overlaps the grid kernel of step k+1 (RCCL runs on
     # its own stream; the buffer is only reused after its gather has completed)
@@ -307,7 +507,7 @@ def main():
         return achieved
 
     traffic = None
-    tfile = ROOT / "profiles" / f"traffic_{work.name}.json"
+    tfile = ROOT / "profiles" / f"traffic_{work.name}.json"  # measured by tools/refresh_profiles.sh
     if tfile.exists():
         try:
             traffic = json.loads(tfile.read_text()).get("hbm_bytes_per_launch")
@@ -323,13 +523,13 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": work.scaling,
         "vs_baseline": None,
         "dtype": work.dtype,
         "data": "synthetic",
         "config": {
             "workload": work.label,
-            "score_func": "intersection_vs_union" if work.name == "c2" else "fuzzy_match",
+            "score_func": "fuzzy_match" if work.name == "c3" else "intersection_vs_union",
             "mode": "RAW",
             "threshold": work.threshold,
             "pairs_per_step": pairs_per_step,
@@ -346,6 +546,7 @@ def main():
             "unit": "GB/s",
             "frac": roof(k_ms) / HBM_PEAK_GBPS,
             "traffic": traffic,
+            "hbm_measured_GBps": None if traffic is None else traffic / (k_ms * 1e-3) / 1e9,
             "kernel_ms": k_ms,
             "algorithmic_bytes_per_launch": work.n * work.m * BYTES_PER_PAIR,
             "compulsory_hbm_bytes_per_launch": work.left.nbytes() + work.right.nbytes() + n_hits * 16,
@@ -360,7 +561,7 @@ def main():
         },
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(work, 6_000_000 if work.name == "c2" else 20_000)
+        result["cpu_baseline"] = cpu_baseline(work, 80_000 if work.name == "c3" else 20_000_000)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -223,11 +223,12 @@ class SetTable:
     def from_nested_arrays(
         cls, ids: np.ndarray, plen: np.ndarray, nlev: np.ndarray, side: str, device,
         categories: Optional[np.ndarray] = None, width: Optional[int] = None,
-        category_mode: int = _lib.CAT_NONE, partition: bool = True,
+        category_mode: int = _lib.CAT_NONE, partition: bool = True, orig: Optional[np.ndarray] = None,
     ) -> "SetTable":
         """Levels table from arrays that already are in suffix-nested layout: ``ids`` [n][w] unique
         per row (negative = padding, valid ids first), ``plen`` [n][L] non-decreasing prefix lengths,
-        ``nlev`` [n] (vectorised path for large synthetic cohorts)."""
+        ``nlev`` [n] (vectorised path for large synthetic cohorts).  ``orig`` = the item ids reported in
+        hits (default 0..n-1; a rank's block of a sharded left side passes its global row numbers)."""
         ids = np.asarray(ids, dtype=np.int32)
         n, w_in = ids.shape
         cnt = (ids >= 0).sum(axis=1).astype(np.int32)
@@ -242,7 +243,7 @@ class SetTable:
         max_levels = -(-plen.shape[1] // 4) * 4
         if plen.shape[1] < max_levels:  # pad with the last value (clamped level index)
             plen = np.concatenate([plen, np.repeat(plen[:, -1:], max_levels - plen.shape[1], axis=1)], axis=1)
-        return cls._finish(ids, cnt, side, device, width, None, nlev=np.asarray(nlev, dtype=np.int32), plen=plen,
+        return cls._finish(ids, cnt, side, device, width, orig, nlev=np.asarray(nlev, dtype=np.int32), plen=plen,
                            cat=categories, max_levels=max_levels, category_mode=category_mode, partition=partition)
 
     @classmethod
@@ -502,9 +503,10 @@ class LevelItems:
 def encode_level_strings(
     left_items: Sequence[Sequence[str]], right_items: Sequence[Sequence[str]], device,
     left_cat: Optional[np.ndarray] = None, right_cat: Optional[np.ndarray] = None,
-    category_mode: int = _lib.CAT_NONE, partition: bool = True,
+    category_mode: int = _lib.CAT_NONE, partition: bool = True, left_offset: int = 0,
 ):
     """Levels-mode fuzzy operands: every level of every item is one (pre-processed) string.
+    ``left_offset`` is added to the left item ids reported in hits (a rank's block of a sharded left side).
 
     With a category predicate (and ``partition``) both sides are PARTITIONED by category: an item
     with k categories becomes k rows, rows are grouped per category, and the kernel only visits
@@ -530,7 +532,7 @@ def encode_level_strings(
                     mode = _lib.CAT_INTERSECT
     do_partition = use_cat and partition
 
-    def side(items, cat):
+    def side(items, cat, offset=0):
         flat: List[str] = []
         first = np.zeros(len(items), dtype=np.int32)
         nlev = np.zeros(len(items), dtype=np.int32)
@@ -559,13 +561,14 @@ def encode_level_strings(
         else:
             item = item[np.argsort(-nlev, kind="stable")]
         li = LevelItems(
-            first=_dev(first[item], device), nlev=_dev(nlev[item], device), orig=_dev(item.astype(np.int32), device),
+            first=_dev(first[item], device), nlev=_dev(nlev[item], device),
+            orig=_dev((item + offset).astype(np.int32), device),
             cat=None if cat is None else _dev(cat[item], device), n=len(item),
             seg=None if seg is None else _dev(seg, device),
             seg_start=None if seg_start is None else _dev(seg_start, device), category_mode=mode,
         )
         return li, table
 
-    l_items, l_table = side(left_items, cats.get("l"))
+    l_items, l_table = side(left_items, cats.get("l"), left_offset)
     r_items, r_table = side(right_items, cats.get("r"))
     return l_items, l_table, r_items, r_table
