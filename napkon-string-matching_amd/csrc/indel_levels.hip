@@ -60,6 +60,14 @@ __device__ __forceinline__ unsigned long long lev_add64(unsigned long long a, un
   return d;
 }
 
+// Load from an LDS byte address held in a register (ds_read_b32 / ds_read_b64).
+template <typename T>
+__device__ __forceinline__ T lev_lds_load(uint32_t addr) {
+  return *reinterpret_cast<const __attribute__((address_space(3))) T*>(addr);
+}
+
+constexpr int kLevBatch = 8;  // left rows scored together, step by step
+
 template <int K>
 __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
     const int32_t* __restrict__ lfirst, const int32_t* __restrict__ lnlev, const int32_t* __restrict__ lorig,
@@ -69,7 +77,8 @@ __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
     const uint8_t* __restrict__ rcodes, const int32_t* __restrict__ rlen, nsm_hit* __restrict__ hits,
     unsigned long long* __restrict__ count, const IndelLevParams p) {
   // K = 1: strings <= 64 code units, text in registers; K = 2 / 4: multi-word LCS of indel_wide.hpp,
-  // text image in LDS.  LDS layout: [wave][pm_stride * K] masks | (K > 1) [wave][16 K][64] text dwords
+  // text image in LDS.  LDS layout: [wave][pm_stride * K] masks | (K > 1) [wave][16 K][64] text dwords |
+  // [wave][kLevBatch][64] running scores
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_pm[];
   constexpr int kRow = kWave * K;  // bytes per string row
   const int waves = blockDim.x >> 6;
@@ -105,30 +114,41 @@ __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
   unsigned long long* pm = s_pm + wave * p.pm_stride * K;
   uint32_t* wtext = reinterpret_cast<uint32_t*>(s_pm + waves * p.pm_stride * K) + wave * 16 * K * kWave;
 
-  uint32_t text[16];
+  // K = 1: the lane's text as LDS addresses of its symbols' match masks (wave's PM base + 8 * code),
+  // two 16-bit fields per VGPR, so one full-rate v_and / v_lshrrev per symbol yields the address; built
+  // once per step and used for every row of the batch
+  uint32_t taddr[32];
+  const uint32_t pm_base = static_cast<uint32_t>(wave * p.pm_stride * K * 8);  // s_pm starts at LDS offset 0
+  uint32_t lowmask = 0xffffu, sh16 = 16u;  // kept in VGPRs: e32 ops with VGPR operands issue at full rate
   int text_row = -1;
   int lb = 0;
+  // running scores of the batch's rows: [row][lane] doubles behind the masks (and the text image)
+  double* sc = reinterpret_cast<double*>(reinterpret_cast<uint32_t*>(s_pm + waves * p.pm_stride * K) +
+                                         (K > 1 ? waves * 16 * K * kWave : 0)) +
+               wave * kLevBatch * kWave;
 
-  // ---- all steps of left row i against the lanes flagged `ok`
-  auto score_row = [&](int i, bool ok) {
-    const int ll = lnlev[i];
-    const int lrow0 = lfirst[i];
-    const int steps_w = max(ll, lr_max);
-    const int steps_l = max(ll, lr);
-    double score = 0.0;
+  auto step_ratio = [](int la_, int lb_, int lcs_) -> double {
+    if constexpr (K == 1) return (la_ == 0 || lb_ == 0) ? 0.0 : g_ratio64.v[(la_ + lb_) * 65 + lcs_];
+    else return indel_score_dev(la_, lb_, lcs_);
+  };
+
+  // ---- rows [ib, ib + nrows) against the lanes flagged in okbits (bit r = row ib + r), STEP-MAJOR: the
+  // lane's right level string of a step is fetched once for the whole batch (row-major order fetched it
+  // per row and step: 3.4 TB of 64-byte reloads per C5 pass, no longer L2-resident at 500k items), and
+  // the wave maximum of the text lengths is taken once per step.  `live` (scalar) = rows some lane can
+  // still bring over the threshold.
+  auto score_batch = [&](int ib, int nrows, uint32_t okbits, uint32_t live) __attribute__((always_inline)) {
+    for (int r = 0; r < nrows; ++r) sc[r * kWave + lane] = 0.0;
+    int steps_max = 0;
+    for (uint32_t rows = live; rows;) {
+      const int r = __builtin_ctz(rows);
+      rows &= rows - 1;
+      steps_max = max(steps_max, max(lnlev[ib + r], lr_max));
+    }
     double factor = 1.0;
-    int pm_row = -1;
-    int la = 0;
-    for (int s = 1; s <= steps_w; ++s) {
-      const bool active = ok && s <= steps_l;
-      // left level (wave-uniform): rebuild the match masks when the level changes
-      const int lrow = lrow0 + max(0, min(s, ll - 1));
-      if (lrow != pm_row) {
-        pm_row = lrow;
-        la = llen[lrow];
-        wide_build_pm<K>(pm, p.pm_stride, lcodes + static_cast<size_t>(lrow) * kRow, la, lane);
-      }
-      // right level (per lane): reload the row only when its index changes
+    for (int s = 1; s <= steps_max && live; ++s) {
+      factor *= 0.5;
+      // right level of this step (per lane): reload the row only when its index changes
       const int rrow = rrow0 + max(0, min(s, lr - 1));
       if constexpr (K == 1) {
         if (rrow != text_row) {
@@ -137,10 +157,13 @@ __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const uint4 v = tp[q];
-            text[4 * q + 0] = v.x;
-            text[4 * q + 1] = v.y;
-            text[4 * q + 2] = v.z;
-            text[4 * q + 3] = v.w;
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const uint32_t c0 = w[e] & 0xffu, c1 = (w[e] >> 8) & 0xffu, c2 = (w[e] >> 16) & 0xffu, c3 = w[e] >> 24;
+              taddr[8 * q + 2 * e + 0] = (pm_base + 8 * c0) | ((pm_base + 8 * c1) << 16);
+              taddr[8 * q + 2 * e + 1] = (pm_base + 8 * c2) | ((pm_base + 8 * c3) << 16);
+            }
           }
           lb = rlen[rrow];
         }
@@ -151,83 +174,101 @@ __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
           lb = rlen[rrow];
         }
       }
-      const int nchars = wave_max_i32(active ? lb : 0);
-      int lcs;
-      if constexpr (K == 1) {
-        const int nwords = (nchars + 3) >> 2;
-        if (la <= 32) {  // wave-uniform: 32-bit words, and / add / xor / or all issue at full rate
-          const uint32_t* pm32 = reinterpret_cast<const uint32_t*>(pm);
-          uint32_t v = ~0u;
-#pragma unroll
-          for (int w = 0; w < 16; ++w) {
-            if (w < nwords) {
-#pragma unroll
-              for (int b = 0; b < 4; ++b) {
-                const unsigned c = (text[w] >> (8 * b)) & 0xffu;
-                const uint32_t m = pm32[2 * c];
-                const uint32_t u = v & m;
-                v = (v + u) | (v ^ u);
-              }
-            }
-          }
-          lcs = 32 - __popc(v);
-        } else {
-          unsigned long long v = ~0ull;
-#pragma unroll
-          for (int w = 0; w < 16; ++w) {
-            if (w < nwords) {
-#pragma unroll
-              for (int b = 0; b < 4; ++b) {
-                const unsigned c = (text[w] >> (8 * b)) & 0xffu;
-                const unsigned long long m = pm[c];
-                const unsigned long long u = v & m;
-                v = lev_add64(v, u) | (v ^ u);
-              }
-            }
-          }
-          lcs = 64 - __popcll(v);
+      const int nchars = wave_max_i32(okbits ? lb : 0);
+      for (uint32_t rows = live; rows;) {
+        const int r = __builtin_ctz(rows);
+        rows &= rows - 1;
+        const int i = ib + r;
+        const int ll = lnlev[i];
+        if (s > max(ll, lr_max)) {  // every lane has seen all its steps of this row
+          live &= ~(1u << r);
+          continue;
         }
-      } else {
-        lcs = wide_lcs<K>(pm, wtext, nchars, lane, la);
+        const bool active = ((okbits >> r) & 1u) && s <= max(ll, lr);
+        // left level (wave-uniform): its match masks
+        const int lrow = lfirst[i] + max(0, min(s, ll - 1));
+        const int la = llen[lrow];
+        wide_build_pm<K>(pm, p.pm_stride, lcodes + static_cast<size_t>(lrow) * kRow, la, lane);
+        int lcs;
+        if constexpr (K == 1) {
+          const int npairs = (nchars + 1) >> 1;
+          // opaque per row: otherwise the 64 unpacked addresses are hoisted out of the row loop into 64
+          // more VGPRs (3 waves/SIMD instead of 6)
+          asm volatile("" : "+v"(lowmask), "+v"(sh16));
+          if (la <= 32) {  // wave-uniform: 32-bit words, and / add / xor / or all issue at full rate
+            uint32_t v = ~0u;
+#pragma unroll
+            for (int w = 0; w < 32; ++w) {
+              if (w < npairs) {
+                const uint32_t m0 = lev_lds_load<uint32_t>(taddr[w] & lowmask);
+                const uint32_t u0 = v & m0;
+                v = (v + u0) | (v ^ u0);
+                const uint32_t m1 = lev_lds_load<uint32_t>(taddr[w] >> sh16);
+                const uint32_t u1 = v & m1;
+                v = (v + u1) | (v ^ u1);
+              }
+            }
+            lcs = 32 - __popc(v);
+          } else {
+            unsigned long long v = ~0ull;
+#pragma unroll
+            for (int w = 0; w < 32; ++w) {
+              if (w < npairs) {
+                const unsigned long long m0 = lev_lds_load<unsigned long long>(taddr[w] & lowmask);
+                const unsigned long long u0 = v & m0;
+                v = lev_add64(v, u0) | (v ^ u0);
+                const unsigned long long m1 = lev_lds_load<unsigned long long>(taddr[w] >> sh16);
+                const unsigned long long u1 = v & m1;
+                v = lev_add64(v, u1) | (v ^ u1);
+              }
+            }
+            lcs = 64 - __popcll(v);
+          }
+        } else {
+          lcs = wide_lcs<K>(pm, wtext, nchars, lane, la);
+        }
+        double score = sc[r * kWave + lane];
+        if (active) {
+          score += step_ratio(la, lb, lcs) * factor;
+          sc[r * kWave + lane] = score;
+        }
+        // exact early exit: the steps still to come add at most factor - 2^-steps < factor (ratios are
+        // <= 1); when no lane can reach the threshold any more the row is dropped.  The 1e-9 keeps the
+        // test safe under the rounding of the double sum.
+        if (!__any(active && (score + factor + 1e-9 >= p.threshold))) live &= ~(1u << r);
       }
-      factor *= 0.5;
-      if (active) {
-        double ratio;
-        if constexpr (K == 1) ratio = (la == 0 || lb == 0) ? 0.0 : g_ratio64.v[(la + lb) * 65 + lcs];
-        else ratio = indel_score_dev(la, lb, lcs);
-        score += ratio * factor;
-      }
-      // exact early exit: the steps still to come add at most factor - 2^-steps < factor (ratios are
-      // <= 1); when no lane can reach the threshold any more the rest of the row is skipped.  The
-      // 1e-9 keeps the test safe under the rounding of the double sum.
-      if (!__any(active && (score + factor + 1e-9 >= p.threshold))) break;
     }
-    const bool hit = ok && score >= p.threshold;
-    if (__any(hit)) {
-      if (hit) emit_hit(hits, p.cap, count, score, lorig[i], jorig);
+    for (int r = 0; r < nrows; ++r) {
+      const double score = sc[r * kWave + lane];
+      const bool hit = ((okbits >> r) & 1u) && score >= p.threshold;
+      if (__any(hit)) {
+        if (hit) emit_hit(hits, p.cap, count, score, lorig[ib + r], jorig);
+      }
     }
   };
 
-  if (partitioned) {
-    // both sides are grouped by category: visit the left rows of the categories this wave's lanes
-    // stand for, and report a pair in its lowest common category only
-    unsigned long long cats = wave_or_u64(valid ? (1ull << myseg) : 0ull);
-    while (cats) {
-      const int c = __builtin_ctzll(cats);
-      cats &= cats - 1;
-      const int a = max(i0, lsegstart[c]);
-      const int b = min(i1, lsegstart[c + 1]);
-      const unsigned long long lower = (1ull << c) - 1ull;
-      for (int i = a; i < b; ++i) {
-        const bool ok = valid && myseg == c && ((lcat[i] & catr & lower) == 0ull);
-        if (__any(ok)) score_row(i, ok);
+  // With a category partition both sides are grouped by category: visit the left rows of the categories
+  // this wave's lanes stand for, and report a pair in its lowest common category only.  Without one:
+  // a single pass over the chunk with the per-lane predicate.
+  unsigned long long cats = partitioned ? wave_or_u64(valid ? (1ull << myseg) : 0ull) : 1ull;
+  while (cats) {
+    const int c = __builtin_ctzll(cats);
+    cats &= cats - 1;
+    const int a = partitioned ? max(i0, lsegstart[c]) : i0;
+    const int b = partitioned ? min(i1, lsegstart[c + 1]) : i1;
+    const unsigned long long lower = (1ull << c) - 1ull;
+    for (int ib = a; ib < b; ib += kLevBatch) {
+      const int nrows = min(kLevBatch, b - ib);
+      uint32_t okbits = 0, live = 0;
+      for (int r = 0; r < nrows; ++r) {
+        const uint64_t cl = (p.cat_mode != NSM_CAT_NONE) ? lcat[ib + r] : 0ull;
+        bool ok = valid;
+        if (partitioned) ok = ok && myseg == c && ((cl & catr & lower) == 0ull);
+        else if (p.cat_mode != NSM_CAT_NONE) ok = ok && category_match(cl, catr, p.cat_mode);
+        okbits |= ok ? (1u << r) : 0u;
+        live |= __any(ok) ? (1u << r) : 0u;
       }
-    }
-  } else {
-    for (int i = i0; i < i1; ++i) {
-      bool ok = valid;
-      if (p.cat_mode != NSM_CAT_NONE) ok = ok && category_match(lcat[i], catr, p.cat_mode);
-      if (__any(ok)) score_row(i, ok);
+      if (live) score_batch(ib, nrows, okbits, live);
     }
   }
 }
@@ -298,9 +339,11 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
     grid.y = (left->n + p.rows_per_chunk - 1) / p.rows_per_chunk;
   }
   const int K = stride / 64;
-  const int waves = K == 4 ? 2 : 4;  // keeps the block under 64 KiB of LDS
+  const size_t lds_wave = p.pm_stride * K * 8 + (K > 1 ? 16 * K * kWave * 4 : 0) + kLevBatch * kWave * 8;
+  int waves = 4;
+  while (waves > 1 && waves * lds_wave > 60 * 1024) waves >>= 1;  // keeps the block under 64 KiB of LDS
   dim3 grid2((n_tiles + waves - 1) / waves, grid.y);
-  const size_t lds = static_cast<size_t>(waves) * (p.pm_stride * K * 8 + (K > 1 ? 16 * K * kWave * 4 : 0));
+  const size_t lds = static_cast<size_t>(waves) * lds_wave;
 #define NSM_LAUNCH_LEVELS(KK)                                                                                  \
   hipLaunchKernelGGL((indel_levels_kernel<KK>), grid2, dim3(waves * kWave), lds, static_cast<hipStream_t>(stream), \
                      left->first, left->nlev, left->orig, left->cat, left->seg_start, left_strings->codes,     \
