@@ -66,7 +66,15 @@ __device__ __forceinline__ T lev_lds_load(uint32_t addr) {
   return *reinterpret_cast<const __attribute__((address_space(3))) T*>(addr);
 }
 
-constexpr int kLevBatch = 8;  // left rows scored together, step by step
+// tunables, A/B-measured on C5-shaped cohorts (3 x 100k^2): batch 4 / 8 / 16 -> 59.3 / 53.7 / 63.1 ms,
+// chunk 64 / 128 / 256 -> 53.2 / 53.7 / 54.8 ms
+#ifndef NSM_LEV_BATCH
+#define NSM_LEV_BATCH 8
+#endif
+#ifndef NSM_LEV_CHUNK
+#define NSM_LEV_CHUNK 128
+#endif
+constexpr int kLevBatch = NSM_LEV_BATCH;  // left rows scored together, step by step
 
 template <int K>
 __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
@@ -331,7 +339,7 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
   if (rows > 4096) rows = 4096;
   // with a category partition a tile only works on the chunks that overlap its categories' row
   // ranges: small chunks, or a handful of long-running waves hold the whole launch
-  if (left->seg && rows > 128) rows = 128;
+  if (left->seg && rows > NSM_LEV_CHUNK) rows = NSM_LEV_CHUNK;
   p.rows_per_chunk = static_cast<int>(rows);
   dim3 grid((n_tiles + kWavesPerBlock - 1) / kWavesPerBlock, (left->n + p.rows_per_chunk - 1) / p.rows_per_chunk);
   if (grid.y > 65535) {

@@ -1,8 +1,12 @@
 #!/bin/bash
-# same-box A/B of two builds of the library on the levels-mode bench: tools/ab_levels.sh old.so [rounds]
-old=$1; rounds=${2:-2}
-show='import sys,json; d=json.loads(sys.stdin.read()); print(sys.argv[1], "fuzzy %.2f ms  jaccard %.3f ms" % (d["fuzzy_match"]["ms_per_3_grids"], d["intersection_vs_union"]["ms_per_3_grids"]))'
-for r in $(seq $rounds); do
-  NSM_HIP_LIBRARY=$old timeout -k 10 300 python tools/bench_levels.py --rows 100000 --steps 5 2>/dev/null | python -c "$show" old || exit 1
-  timeout -k 10 300 python tools/bench_levels.py --rows 100000 --steps 5 2>/dev/null | python -c "$show" new || exit 1
+# same-box comparison of builds of the library on the levels-mode bench:
+#   tools/ab_levels.sh [--rows N] lib_a.so lib_b.so ...      ("-" = the in-tree build)
+rows=100000
+if [ "$1" = "--rows" ]; then rows=$2; shift 2; fi
+show='import sys,json; d=json.loads(sys.stdin.read()); print("%-28s fuzzy %8.2f ms  jaccard %7.3f ms" % (sys.argv[1], d["fuzzy_match"]["ms_per_3_grids"], d["intersection_vs_union"]["ms_per_3_grids"]))'
+for round in 1 2; do
+  for lib in "$@"; do
+    if [ "$lib" = "-" ]; then unset NSM_HIP_LIBRARY; else export NSM_HIP_LIBRARY=$lib; fi
+    timeout -k 10 600 python tools/bench_levels.py --rows $rows --steps 4 2>/dev/null | python -c "$show" "$(basename $lib)" || exit 1
+  done
 done
