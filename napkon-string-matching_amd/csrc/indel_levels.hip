@@ -74,7 +74,9 @@ __device__ __forceinline__ T lev_lds_load(uint32_t addr) {
 #ifndef NSM_LEV_CHUNK
 #define NSM_LEV_CHUNK 128
 #endif
-constexpr int kLevBatch = NSM_LEV_BATCH;  // left rows scored together, step by step
+// left rows scored together, step by step; the 4-word kernel already spends 18 KB of LDS per wave on
+// masks and text image, 4 rows (2 KB of scores) keep 8 waves per CU
+constexpr int lev_batch(int K) { return K == 4 ? NSM_LEV_BATCH / 2 : NSM_LEV_BATCH; }
 
 template <int K>
 __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
@@ -86,9 +88,10 @@ __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
     unsigned long long* __restrict__ count, const IndelLevParams p) {
   // K = 1: strings <= 64 code units, text in registers; K = 2 / 4: multi-word LCS of indel_wide.hpp,
   // text image in LDS.  LDS layout: [wave][pm_stride * K] masks | (K > 1) [wave][16 K][64] text dwords |
-  // [wave][kLevBatch][64] running scores
+  // [wave][lev_batch(K)][64] running scores
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_pm[];
   constexpr int kRow = kWave * K;  // bytes per string row
+  constexpr int kBatch = lev_batch(K);
   const int waves = blockDim.x >> 6;
 
   const int lane = threadIdx.x & (kWave - 1);
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
   // running scores of the batch's rows: [row][lane] doubles behind the masks (and the text image)
   double* sc = reinterpret_cast<double*>(reinterpret_cast<uint32_t*>(s_pm + waves * p.pm_stride * K) +
                                          (K > 1 ? waves * 16 * K * kWave : 0)) +
-               wave * kLevBatch * kWave;
+               wave * kBatch * kWave;
 
   auto step_ratio = [](int la_, int lb_, int lcs_) -> double {
     if constexpr (K == 1) return (la_ == 0 || lb_ == 0) ? 0.0 : g_ratio64.v[(la_ + lb_) * 65 + lcs_];
@@ -265,8 +268,8 @@ __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
     const int a = partitioned ? max(i0, lsegstart[c]) : i0;
     const int b = partitioned ? min(i1, lsegstart[c + 1]) : i1;
     const unsigned long long lower = (1ull << c) - 1ull;
-    for (int ib = a; ib < b; ib += kLevBatch) {
-      const int nrows = min(kLevBatch, b - ib);
+    for (int ib = a; ib < b; ib += kBatch) {
+      const int nrows = min(kBatch, b - ib);
       uint32_t okbits = 0, live = 0;
       for (int r = 0; r < nrows; ++r) {
         const uint64_t cl = (p.cat_mode != NSM_CAT_NONE) ? lcat[ib + r] : 0ull;
@@ -347,7 +350,7 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
     grid.y = (left->n + p.rows_per_chunk - 1) / p.rows_per_chunk;
   }
   const int K = stride / 64;
-  const size_t lds_wave = p.pm_stride * K * 8 + (K > 1 ? 16 * K * kWave * 4 : 0) + kLevBatch * kWave * 8;
+  const size_t lds_wave = p.pm_stride * K * 8 + (K > 1 ? 16 * K * kWave * 4 : 0) + lev_batch(K) * kWave * 8;
   int waves = 4;
   while (waves > 1 && waves * lds_wave > 60 * 1024) waves >>= 1;  // keeps the block under 64 KiB of LDS
   dim3 grid2((n_tiles + waves - 1) / waves, grid.y);
