@@ -54,7 +54,10 @@ typedef struct nsm_hit {
  *   cnt   device int32 [n]         number of ids in the row (RAW) / in the item's largest level
  *   sig   device uint64[n]         signature word: bits 0..57 = OR over the row's ids of
  *                                  1 << ((((id * 0x9E3779B1u) >> 16) & 0xffff) * 58 >> 16); bits 58..63 =
- *                                  min(63, cnt - popcount(bits 0..57)) (ids that collided inside the row)
+ *                                  the low c of them set, c = cnt - popcount(bits 0..57) (ids that collided
+ *                                  inside the row); a row with c > 6 has all 64 bits set.  The kernels force
+ *                                  bits 58..63 of the OTHER side's word to one, so that
+ *                                  popcount(a & b) = common hash bits + c >= |A n B|
  *   sig2  device uint64[n]         second, independent signature word (multiplier 0xC2B2AE35u);
  *                                  optional (NULL: the prune has one stage)
  *   orig  device int32 [n]         caller's row id reported in hits

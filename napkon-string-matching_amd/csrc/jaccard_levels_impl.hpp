@@ -172,9 +172,10 @@ __device__ __forceinline__ void levels_wave(
   auto filter_row = [&](uint32_t sig_lo, uint32_t sig_hi, uint32_t cat_lo, uint32_t cat_hi, uint32_t sig1_lo,
                         uint32_t sig1_hi) {
     int bound, bound1;
-    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(bound) : "v"(sig_lo & sr_lo), "s"(sig_hi >> 26));
+    // (the right words come with their top 6 bits set: the AND keeps the row's unary collision count)
+    asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(bound) : "v"(sig_lo & sr_lo));
     asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(bound) : "v"(sig_hi & sr_hi), "v"(bound));
-    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(bound1) : "v"(sig1_lo & sr1_lo), "s"(sig1_hi >> 26));
+    asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(bound1) : "v"(sig1_lo & sr1_lo));
     asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(bound1) : "v"(sig1_hi & sr1_hi), "v"(bound1));
     bound = min(bound, pr1) + bound1;
     bool pass = bound >= need_r;
@@ -282,9 +283,10 @@ __global__ __launch_bounds__(kBlock) void jaccard_levels_kernel(
     r[4 * q + 3] = (v.w << 6) | (4 * q + 3);
   }
   const int nrj = valid ? rcnt[jc] : 0;
-  const uint64_t sr = valid ? (rsig[jc] & ((1ull << 58) - 1)) : 0ull;  // hash bits only
+  constexpr uint64_t kCollBits = ~((1ull << 58) - 1);  // top 6 bits: the OTHER side's unary collision count
+  const uint64_t sr = valid ? (rsig[jc] | kCollBits) : 0ull;
   const uint32_t* rf = rfilt + static_cast<size_t>(jc) * 8;
-  const uint64_t sr1 = valid ? (((static_cast<uint64_t>(rf[6]) << 32) | rf[5]) & ((1ull << 58) - 1)) : 0ull;
+  const uint64_t sr1 = valid ? (((static_cast<uint64_t>(rf[6]) << 32) | rf[5]) | kCollBits) : 0ull;
   const uint64_t catr = (p.cat_mode != NSM_CAT_NONE) ? rcat[jc] : 0ull;
   const int lr = rnlev[jc];
   const int jorig = rorig[jc];

@@ -100,27 +100,27 @@ __device__ __forceinline__ void class_rows(const int32_t* __restrict__ lids,
     }
   };
   if (PRUNE && use_prune) {
-    // |A n B| <= popcount(hashbits(A) & hashbits(B)) + cA.  A signature word holds 58 hash bits and,
-    // in its top 6 bits, cA = the ids of the row that share a hash bit with an earlier id of the
-    // same row (|A| - popcount(hashbits)): common ids that collide inside the row are the only ones
-    // the AND can miss.  (sr, sr2 come with their top 6 bits cleared.)
-    // Per row: 2 v_and + 2 v_bcnt (chained accumulate, seeded with the scalar cA) + v_cmp +
-    // v_addc (shifts the verdict into a per-lane bit mask) = 6 VALU and 1 SALU; the scalar unit is
-    // shared by the CU's 4 SIMDs, so the verdicts are NOT collected with s_cselect/s_or.
-    // (Tried: keep the 8 bounds and reduce them with v_max3 + one compare per batch -- 4.6 VALU per
-    // row instead of 6, yet 19 % SLOWER in a same-device A/B: 0.591 vs 0.497 ms on C2.)
+    // |A n B| <= popcount(hashbits(A) & hashbits(B)) + cA, cA = the ids of the row that share a hash
+    // bit with an earlier id of the same row: common ids that collide inside the row are the only
+    // ones the AND can miss.  A signature word holds 58 hash bits and cA in unary in its top 6 bits;
+    // sr / sr2 come with their top 6 bits SET, so the bound is just popcount(sl & sr).
+    // Per row: 2 v_and + 2 v_bcnt (chained, seeded with the lane's -need) + 1 full-rate v_and that
+    // folds the sign (bound - need < 0 = cannot reach the threshold) into the batch's verdict = 5
+    // VALU; the scalar unit is shared by the CU's 4 SIMDs, so verdicts are NOT collected with
+    // s_cselect/s_or.  (Before: cA as a number in the top bits, v_cmp + v_addc per row: 6 VALU, the
+    // last two at half rate.  Tried earlier: reduce 8 bounds with v_max3 -- slower, see DESIGN.md.)
     constexpr int BATCH = 8;
-    auto bound_of = [&](uint64_t sl, uint64_t srm) {
-      const int extra_l = static_cast<int>(sl >> 58);  // SALU
+    const int neg_need = -need;
+    auto margin_of = [&](uint64_t sl, uint64_t srm) {  // bound - need
       const uint32_t lo = static_cast<uint32_t>(sl) & static_cast<uint32_t>(srm);
       const uint32_t hi = static_cast<uint32_t>(sl >> 32) & static_cast<uint32_t>(srm >> 32);
-      int bound;
-      asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(bound) : "v"(lo), "s"(extra_l));
-      asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(bound) : "v"(hi), "v"(bound));
-      return bound;
+      int margin;
+      asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(margin) : "v"(lo), "v"(neg_need));
+      asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(margin) : "v"(hi), "v"(margin));
+      return margin;
     };
     auto second_stage = [&](int i) {
-      return lsig2 == nullptr || __any(bound_of(lsig2[i], sr2) >= need);
+      return lsig2 == nullptr || __any(margin_of(lsig2[i], sr2) >= 0);
     };
     int i = a;
     if (i + BATCH <= b) {
@@ -133,16 +133,19 @@ __device__ __forceinline__ void class_rows(const int32_t* __restrict__ lids,
         uint64_t nxt[BATCH];
 #pragma unroll
         for (int q = 0; q < BATCH; ++q) nxt[q] = lsig[inext + q];
-        uint32_t cand = 0;  // per lane: bit (BATCH-1-q) = row q may reach the threshold
+        int margin[BATCH];
+        int all_fail = -1;  // sign bit stays set while every row of the batch fails
 #pragma unroll
         for (int q = 0; q < BATCH; ++q) {
-          const int bound = bound_of(cur[q], sr);
-          asm("v_cmp_ge_i32 vcc, %1, %2\n\ts_nop 1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
-              : "+v"(cand) : "v"(bound), "v"(need) : "vcc");
+          margin[q] = margin_of(cur[q], sr);
+          all_fail &= margin[q];
         }
-        if (__any(cand != 0)) {  // rare
+        if (__any(all_fail >= 0)) {  // rare
+          uint32_t cand = 0;  // per lane: bit q = row q may reach the threshold
+#pragma unroll
+          for (int q = 0; q < BATCH; ++q) cand |= margin[q] >= 0 ? (1u << q) : 0u;
           for (int q = 0; q < BATCH; ++q) {  // ONE copy of the matrix body (I-cache footprint)
-            if (__any((cand >> (BATCH - 1 - q)) & 1u)) {
+            if (__any((cand >> q) & 1u)) {
               // second stage: an independent signature must agree before the matrix is paid for
               if (second_stage(i + q)) exact_row(i + q);
             }
@@ -153,7 +156,7 @@ __device__ __forceinline__ void class_rows(const int32_t* __restrict__ lids,
       }
     }
     for (; i < b; ++i) {
-      if (__any(bound_of(lsig[i], sr) >= need) && second_stage(i)) exact_row(i);
+      if (__any(margin_of(lsig[i], sr) >= 0) && second_stage(i)) exact_row(i);
     }
   } else {
     for (int i = a; i < b; ++i) exact_row(i);
@@ -242,9 +245,9 @@ __global__ __launch_bounds__(kBlock) void jaccard_raw_kernel(
     r[4 * q + 3] = v.w;
   }
   const int nrj = valid ? rcnt[jc] : 0;
-  constexpr uint64_t kHashBits = (1ull << 58) - 1;  // the top 6 bits of a signature word hold cA
-  const uint64_t sr = (PRUNE && valid) ? (rsig[jc] & kHashBits) : 0ull;
-  const uint64_t sr2 = (PRUNE && valid && rsig2 != nullptr) ? (rsig2[jc] & kHashBits) : 0ull;
+  constexpr uint64_t kCollBits = ~((1ull << 58) - 1);  // the top 6 bits of a signature word hold cA (unary)
+  const uint64_t sr = (PRUNE && valid) ? (rsig[jc] | kCollBits) : 0ull;
+  const uint64_t sr2 = (PRUNE && valid && rsig2 != nullptr) ? (rsig2[jc] | kCollBits) : 0ull;
   if (rsig2 == nullptr) lsig2 = nullptr;
   const int jorig = rorig[jc];
   const int nbmax = wave_first(nrj);  // sorted descending: lane 0 holds the tile's largest set

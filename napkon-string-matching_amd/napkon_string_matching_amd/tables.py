@@ -54,8 +54,10 @@ def pick_stride(max_len: int) -> int:
 
 
 def signatures(ids: np.ndarray, cnt: np.ndarray, multiplier: np.uint32 = _GOLDEN) -> np.ndarray:
-    """Signature word per row (include/nsm_hip.h): 58 hash bits, and in the top 6 bits the number
-    of ids that collided with an earlier id of the same row (saturating at 63)."""
+    """Signature word per row (include/nsm_hip.h): 58 hash bits; the top 6 bits hold, in UNARY, the
+    number c of ids that collided with an earlier id of the same row, so that with the other side's
+    top bits forced to one popcount(a & b) = popcount(common hash bits) + c >= |A n B|.  A row with
+    c > 6 is all ones (always passes; both sides encode it that way)."""
     n, w = ids.shape
     if not n:
         return np.zeros(0, np.uint64)
@@ -64,8 +66,9 @@ def signatures(ids: np.ndarray, cnt: np.ndarray, multiplier: np.uint32 = _GOLDEN
     pos = ((h16.astype(np.uint64) * np.uint64(58)) >> np.uint64(16)).astype(np.uint64)
     bits = np.where(valid, np.uint64(1) << pos, np.uint64(0))
     word = np.bitwise_or.reduce(bits, axis=1)
-    extra = np.minimum(63, cnt.astype(np.int64) - np.bitwise_count(word).astype(np.int64)).astype(np.uint64)
-    return word | (extra << np.uint64(58))
+    extra = cnt.astype(np.int64) - np.bitwise_count(word).astype(np.int64)
+    unary = ((np.uint64(1) << np.minimum(extra, 6).astype(np.uint64)) - np.uint64(1)) << np.uint64(58)
+    return np.where(extra > 6, np.uint64(0xFFFFFFFFFFFFFFFF), word | unary)
 
 
 def _dev(array: np.ndarray, device) -> torch.Tensor:
