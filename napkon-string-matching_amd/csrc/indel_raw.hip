@@ -195,27 +195,34 @@ __global__ __launch_bounds__(kBlock) void indel_raw_kernel(
         }
       };
       // 4 rows per iteration: their 32 histogram dwords arrive with two s_load_dwordx16 issued
-      // back to back, the verdicts are shifted into a per-lane bit mask on the VALU side
-      // (v_cmp + v_addc) -- the scalar unit is shared by the CU's 4 SIMDs, keep it idle.
+      // back to back.  The SAD chain of a row is seeded with -(limit + 1), so its result is negative
+      // exactly when L1 <= limit; one full-rate v_or per row folds the signs into the batch's verdict
+      // (the scalar unit is shared by the CU's 4 SIMDs, keep it idle; v_cmp + v_addc per row cost
+      // two half-rate ops).
       constexpr int BATCH = 4;
+      const uint32_t seed = static_cast<uint32_t>(-(limit + 1));
       const uint32_t* __restrict__ hp = lhist + static_cast<size_t>(a) * 8;
       int i = a;
       for (; i + BATCH <= b; i += BATCH, hp += 8 * BATCH) {
         uint32_t h[8 * BATCH];
 #pragma unroll
         for (int q = 0; q < 8 * BATCH; ++q) h[q] = hp[q];
-        uint32_t cand = 0;  // bit (BATCH-1-r) = row r may reach the threshold
+        int margin[BATCH];
+        int any_pass = 0;  // sign bit set when some row of the batch may reach the threshold
 #pragma unroll
         for (int r = 0; r < BATCH; ++r) {
-          uint32_t l1 = 0;
+          uint32_t l1 = seed;
 #pragma unroll
           for (int q = 0; q < 8; ++q) l1 = __builtin_amdgcn_sad_u8(h[8 * r + q], hr[q], l1);
-          asm("v_cmp_le_i32 vcc, %1, %2\n\ts_nop 1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
-              : "+v"(cand) : "v"(static_cast<int>(l1)), "v"(limit) : "vcc");
+          margin[r] = static_cast<int>(l1);
+          any_pass |= margin[r];
         }
-        if (__any(cand != 0)) {  // rare
+        if (__any(any_pass < 0)) {  // rare
+          uint32_t cand = 0;
+#pragma unroll
+          for (int r = 0; r < BATCH; ++r) cand |= margin[r] < 0 ? (1u << r) : 0u;
           for (int r = 0; r < BATCH; ++r)
-            if (__any((cand >> (BATCH - 1 - r)) & 1u)) score_row(i + r);
+            if (__any((cand >> r) & 1u)) score_row(i + r);
         }
       }
       for (; i < b; ++i, hp += 8) {
