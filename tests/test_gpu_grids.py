@@ -225,6 +225,11 @@ def test_jaccard_levels_random(dev, vocab, max_levels, max_new):
     rng = random.Random(vocab + max_levels)
     left = [_nested_item(rng, vocab, max_levels, max_new) for _ in range(230)]
     right = [_nested_item(rng, vocab, max_levels, max_new) for _ in range(310)]
+    for k in range(0, 300, 7):  # near-duplicates, so that the high thresholds have hits
+        src = [list(lv) for lv in left[rng.randrange(len(left))]]
+        if k % 14 == 0 and len(src) > 1:
+            src = src[:-1]
+        right[k] = src
     lcat = np.array([rng.choice([0, 1, 2, 3, 6]) for _ in left], dtype=np.uint64)
     rcat = np.array([rng.choice([0, 1, 2, 4, 5]) for _ in right], dtype=np.uint64)
     width = tables.pick_width(max(len(it[-1]) for it in left + right))
@@ -236,8 +241,9 @@ def test_jaccard_levels_random(dev, vocab, max_levels, max_new):
         rt = tables.SetTable.from_levels(right, "right", dev, vocabulary, width=width, categories=rcat,
                                          category_mode=mode, partition=partition)
         assert (lt.seg is not None) == (partition and mode != _lib.CAT_NONE)
-        for thr in (0.0, 0.1, 0.3, 0.6):
+        for thr in (0.0, 0.1, 0.3, 0.6, 0.8, 0.93):
             want = native.levels(False, left, right, thr, lcat, rcat, mode, cap=1 << 17)
+            assert thr > 0.9 or len(want) > 0
             got = grid.jaccard_levels_grid(lt, rt, thr, category_mode=mode, capacity=1 << 12)
             _same_hits(got, want)
 
@@ -271,6 +277,10 @@ def test_indel_levels_random(dev, max_levels):
         ]
 
     left, right = [item() for _ in range(90)], [item() for _ in range(140)]
+    for k in range(0, 140, 6):  # near-duplicates: one level string slightly changed
+        src = list(left[rng.randrange(len(left))])
+        src[-1] = src[-1][:-1] + "zz"
+        right[k] = src
     lcat = np.array([rng.choice([0, 1, 2, 3]) for _ in left], dtype=np.uint64)
     rcat = np.array([rng.choice([0, 1, 2]) for _ in right], dtype=np.uint64)
     cps = lambda items: [[[ord(c) for c in s] for s in it] for it in items]
@@ -278,7 +288,7 @@ def test_indel_levels_random(dev, max_levels):
                             (_lib.CAT_INTERSECT_OR_BOTH_EMPTY, False)):
         li, ls, ri, rs = tables.encode_level_strings(left, right, dev, lcat, rcat, mode, partition=partition)
         assert (li.seg is not None) == (partition and mode != _lib.CAT_NONE)
-        for thr in (0.0, 0.25, 0.5):
+        for thr in (0.0, 0.25, 0.5, 0.8):
             want = native.levels(True, cps(left), cps(right), thr, lcat, rcat, mode, cap=1 << 16)
             got = grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, capacity=1 << 11)
             _same_hits(got, want, FUZZY_TOL)
