@@ -95,6 +95,45 @@ def test_jaccard_raw_edges(dev):
         grid.jaccard_raw_grid(lt, lt, 0.5)  # both encoded as 'left': same padding value
 
 
+def test_jaccard_signature_collisions(dev):
+    """Rows whose ids all fall on ONE signature bit: up to 6 in-row collisions ride in the word's top
+    bits, rows with more are encoded as all ones (always pass the bound).  RAW and levels grids."""
+    from napkon_string_matching_amd import grid, tables
+    from oracle import native
+
+    cand = np.arange(400_000, dtype=np.int32)
+    h16 = ((cand.astype(np.uint32) * np.uint32(0x9E3779B1)) >> np.uint32(16)) & np.uint32(0xFFFF)
+    same = cand[((h16.astype(np.uint64) * np.uint64(58)) >> np.uint64(16)) == 5]  # every id lands on bit 5
+    assert len(same) > 64
+    rng = random.Random(5)
+    rows = []
+    for k in (2, 5, 7, 8, 12, 16):  # 1 .. 15 collisions inside the row
+        base = rng.sample(list(map(int, same)), k)
+        rows += [base, base[: max(1, k - 1)] + [int(same[-1])], base[: k // 2 + 1] + rng.sample(range(1000), 3)]
+    rows += [rng.sample(range(5000), rng.randint(1, 12)) for _ in range(80)]
+    left = [list(dict.fromkeys(r))[:16] for r in rows]
+    right = [list(r) for r in left[::-1]] + [rng.sample(list(map(int, same)), 10) for _ in range(30)]
+    sig = tables.signatures(np.array([left[15] + [-1] * (16 - len(left[15]))], dtype=np.int32), np.array([len(left[15])], np.int32))
+    assert int(sig[0]) == (1 << 64) - 1  # 16 ids on one bit: 15 collisions -> all ones
+    # (from_rows would renumber the tokens: encode the raw ids, so that the hash positions are the crafted ones)
+    pad = lambda rr: np.array([r + [-1] * (16 - len(r)) for r in rr], dtype=np.int32)
+    lt, rt = tables.SetTable.from_padded(pad(left), "left", dev), tables.SetTable.from_padded(pad(right), "right", dev)
+    for thr in (0.2, 0.5, 0.8, 1.0):
+        want = native.jaccard_raw(native.csr(left), native.csr(right), thr, cap=1 << 16)
+        assert len(want) > 5
+        for prune in (True, False):
+            _same_hits(grid.jaccard_raw_grid(lt, rt, thr, prune=prune), want)
+    # levels: each row as a two-level item (first half, whole row)
+    items = lambda rr: [[r[: max(1, len(r) // 2)], r] for r in rr]
+    nested = lambda rr, side: tables.SetTable.from_nested_arrays(
+        pad(rr), np.array([[max(1, len(r) // 2), len(r)] for r in rr], dtype=np.uint8), np.full(len(rr), 2, np.int32), side, dev)
+    lt2, rt2 = nested(left, "left"), nested(right, "right")
+    for thr in (0.2, 0.5, 0.7):
+        want = native.levels(False, items(left), items(right), thr, cap=1 << 16)
+        assert len(want) > 5
+        _same_hits(grid.jaccard_levels_grid(lt2, rt2, thr), want)
+
+
 def _rand_strings(rng, n, alphabet, lo, hi):
     out = []
     for _ in range(n):
