@@ -256,3 +256,26 @@ def test_results_writers(tmp_path):
     produced = list(tmp_path.glob("result_0.7_Term_fuzzy-match*"))
     assert produced
     assert m._analyse() == {"hap vs pop": {"matched": "1/1", "gecco": "0/1"}}
+
+
+def test_signature_word_layout():
+    """include/nsm_hip.h: 58 hash bits, in-row collisions in unary in the top 6 bits, all ones beyond 6."""
+    from napkon_string_matching_amd import tables
+
+    cand = np.arange(400_000, dtype=np.int32)
+    h16 = ((cand.astype(np.uint32) * np.uint32(0x9E3779B1)) >> np.uint32(16)) & np.uint32(0xFFFF)
+    pos = (h16.astype(np.uint64) * np.uint64(58)) >> np.uint64(16)
+    on5, on9 = cand[pos == 5], cand[pos == 9]
+    for k in range(1, 10):
+        row = np.full((1, 16), -1, dtype=np.int32)
+        row[0, :k] = on5[:k]
+        row[0, k] = on9[0]
+        word = int(tables.signatures(row, np.array([k + 1], np.int32))[0])
+        if k - 1 > 6:
+            assert word == (1 << 64) - 1
+        else:
+            assert word & ((1 << 58) - 1) == (1 << 5) | (1 << 9)
+            assert word >> 58 == (1 << (k - 1)) - 1  # k ids on one bit: k - 1 collisions
+    # an id beyond cnt is ignored
+    row = np.array([[int(on5[0]), int(on9[0])] + [-1] * 14], dtype=np.int32)
+    assert int(tables.signatures(row, np.array([1], np.int32))[0]) == 1 << 5
