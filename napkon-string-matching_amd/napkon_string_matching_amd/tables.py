@@ -179,45 +179,57 @@ class SetTable:
         """Levels table.  ``items[k]`` is the level list of item k (``gen_comp_value`` output,
         types/comparable_data.py:283-285): level l must contain level l-1 (suffix nesting)."""
         n = len(items)
-        orders: List[List[int]] = []
-        plens: List[List[int]] = []
-        ids_of = vocab._ids  # token -> id, filled in place (one dict lookup per token)
-        for k, levels in enumerate(items):
-            if len(levels) > MAX_LEVELS:
-                raise NotImplementedError(f"item {k} has {len(levels)} levels > {MAX_LEVELS}")
-            seen: Dict[int, None] = {}
-            pl: List[int] = []
-            for level in levels:
-                here = []
-                for tok in level:
-                    got = ids_of.get(tok)
-                    if got is None:
-                        got = len(ids_of)
-                        ids_of[tok] = got
-                    here.append(got)
-                seen.update(dict.fromkeys(here))
-                if len(set(here)) != len(seen):
-                    # some earlier id is missing from this level: not suffix-nested
-                    raise NotImplementedError(
-                        f"item {k}: level {len(pl)} does not contain level {len(pl) - 1}; only "
-                        "suffix-nested levels (what gen_comp_value produces) are supported on the GPU"
-                    )
-                pl.append(len(seen))
-            orders.append(list(seen))
-            plens.append(pl)
-        width = width or pick_width(max((len(o) for o in orders), default=1))
-        max_levels = max(4, -(-max((len(p) for p in plens), default=1) // 4) * 4)
+        nlev = np.fromiter((len(levels) for levels in items), dtype=np.int64, count=n)
+        if n and int(nlev.max()) > MAX_LEVELS:
+            k = int(np.argmax(nlev > MAX_LEVELS))
+            raise NotImplementedError(f"item {k} has {int(nlev[k])} levels > {MAX_LEVELS}")
+        n_levels = int(nlev.sum())
+        level_len = np.fromiter((len(level) for levels in items for level in levels), dtype=np.int64, count=n_levels)
+        ids_of = vocab._ids  # token -> id, new tokens numbered in order of first appearance
+        flat = np.fromiter(
+            (ids_of.setdefault(tok, len(ids_of)) for levels in items for level in levels for tok in level),
+            dtype=np.int64, count=int(level_len.sum()))
+        # per token occurrence: its item and its level inside the item
+        level_item = np.repeat(np.arange(n, dtype=np.int64), nlev)
+        level_start = np.zeros(n, dtype=np.int64)
+        np.cumsum(nlev[:-1], out=level_start[1:])
+        level_in_item = np.arange(n_levels, dtype=np.int64) - np.repeat(level_start, nlev)
+        tok_item = np.repeat(level_item, level_len)
+        tok_level = np.repeat(level_in_item, level_len)
+        span = max(1, len(ids_of))
+        # unique ids of an item in first-appearance order (= level order): one row, level l = a prefix
+        _, first = np.unique(tok_item * span + flat, return_index=True)
+        first.sort()
+        u_item, u_id, u_level = tok_item[first], flat[first], tok_level[first]
+        per_item = np.bincount(u_item, minlength=n)[:n]
+        item_start = np.zeros(n, dtype=np.int64)
+        np.cumsum(per_item[:-1], out=item_start[1:])
+        rank = np.arange(len(first), dtype=np.int64) - item_start[u_item]
+        width = width or pick_width(int(per_item.max()) if n else 1)
+        if n and int(per_item.max()) > width:
+            k = int(np.argmax(per_item > width))
+            raise ValueError(f"item {k} has {int(per_item[k])} ids > width {width}")
         ids = np.full((n, width), -1, dtype=np.int32)
-        plen = np.zeros((n, max_levels), dtype=np.uint8)
-        nlev = np.zeros(n, dtype=np.int32)
-        for k, (o, pl) in enumerate(zip(orders, plens)):
-            if len(o) > width:
-                raise ValueError(f"item {k} has {len(o)} ids > width {width}")
-            ids[k, : len(o)] = o
-            nlev[k] = len(pl)
-            plen[k, : len(pl)] = pl
-            if pl:
-                plen[k, len(pl):] = pl[-1]
+        ids[u_item, rank] = u_id
+        max_levels = max(4, -(-(int(nlev.max()) if n else 1) // 4) * 4)
+        # plen[k][l] = ids first seen at a level <= l; levels past the item's last repeat its last value
+        new_at = np.zeros((n, max_levels), dtype=np.int64)
+        np.add.at(new_at, (u_item, u_level), 1)
+        plen_full = np.cumsum(new_at, axis=1)
+        # suffix nesting: level l must hold every id seen before it, i.e. its own distinct ids == plen[l]
+        distinct = np.zeros((n, max_levels), dtype=np.int64)
+        if len(flat):
+            lev_key = np.unique((tok_item * max_levels + tok_level) * span + flat) // span
+            np.add.at(distinct, (lev_key // max_levels, lev_key % max_levels), 1)
+        live = np.arange(max_levels)[None, :] < nlev[:, None]
+        bad = live & (distinct != plen_full)
+        if bad.any():
+            k, lv = (int(v[0]) for v in np.nonzero(bad))
+            raise NotImplementedError(
+                f"item {k}: level {lv} does not contain level {lv - 1}; only suffix-nested levels (what "
+                "gen_comp_value produces) are supported on the GPU")
+        plen = plen_full.astype(np.uint8)
+        nlev = nlev.astype(np.int32)
         cnt = (ids >= 0).sum(axis=1).astype(np.int32)
         return cls._finish(ids, cnt, side, device, width, None, nlev=nlev, plen=plen, cat=categories,
                            max_levels=max_levels, category_mode=category_mode, partition=partition)
