@@ -50,6 +50,7 @@ def parse_args():
     ap.add_argument("--right-rows", type=int, default=0, help="override the right side's rows (debug)")
     ap.add_argument("--threshold", type=float, default=None, help="override the workload's threshold (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", type=int, default=0, help="1: replay each step as one captured hipGraph")
     ap.add_argument("--capacity", type=int, default=1 << 13)
     ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
                     help="gloo = CPU-staged rehearsal of the N > 1 path (e.g. 2 ranks sharing one GPU)")
@@ -435,6 +436,23 @@ def main():
     lib = work.lib
     step_no = [0]
 
+    # The three dependent launches of a step (zero the counter, grid kernel, hit ordering) are captured
+    # once per hit buffer and mode into a hipGraph and replayed: one submission per step.
+    graphs = {}
+
+    def step_graph(k, prune):
+        key = (k, prune)
+        if key not in graphs:
+            b = bufs[k]
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                s = torch.cuda.current_stream(device).cuda_stream
+                b.count.zero_()
+                work.launch(b, s, prune)
+                lib.nsm_sort_hits(b.records.data_ptr(), b.scratch.data_ptr(), b.capacity, b.count.data_ptr(), s)
+            graphs[key] = g
+        return graphs[key]
+
     def step(prune=True):
         k = step_no[0] & 1
         step_no[0] += 1
@@ -442,9 +460,12 @@ def main():
         if pending[k] is not None:
             pending[k].wait()
             pending[k] = None
-        b.count.zero_()
-        work.launch(b, stream, prune)
-        lib.nsm_sort_hits(b.records.data_ptr(), b.scratch.data_ptr(), b.capacity, b.count.data_ptr(), stream)
+        if args.graph:
+            step_graph(k, prune).replay()
+        else:
+            b.count.zero_()
+            work.launch(b, stream, prune)
+            lib.nsm_sort_hits(b.records.data_ptr(), b.scratch.data_ptr(), b.capacity, b.count.data_ptr(), stream)
         if world > 1:
             pending[k] = gather_hits(b, gathered[k], world, device, async_op=True)
 

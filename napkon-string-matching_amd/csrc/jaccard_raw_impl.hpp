@@ -122,37 +122,48 @@ __device__ __forceinline__ void class_rows(const int32_t* __restrict__ lids,
     auto second_stage = [&](int i) {
       return lsig2 == nullptr || __any(margin_of(lsig2[i], sr2) >= 0);
     };
-    int i = a;
-    if (i + BATCH <= b) {
-      // software pipeline: the signatures of batch k+1 are in flight while batch k is tested
-      uint64_t cur[BATCH];
+    // one batch: 8 rows' signature words (already in SGPRs) against the lane's
+    auto test_batch = [&](const uint64_t (&sg)[BATCH], int i) {
+      int margin[BATCH];
+      int all_fail = -1;  // sign bit stays set while every row of the batch fails
 #pragma unroll
-      for (int q = 0; q < BATCH; ++q) cur[q] = lsig[i + q];  // one s_load_dwordx16
-      for (; i + BATCH <= b; i += BATCH) {
-        const int inext = (i + 2 * BATCH <= b) ? i + BATCH : i;  // last batch re-reads itself
-        uint64_t nxt[BATCH];
+      for (int q = 0; q < BATCH; ++q) {
+        margin[q] = margin_of(sg[q], sr);
+        all_fail &= margin[q];
+      }
+      if (__any(all_fail >= 0)) {  // rare
+        uint32_t cand = 0;  // per lane: bit q = row q may reach the threshold
 #pragma unroll
-        for (int q = 0; q < BATCH; ++q) nxt[q] = lsig[inext + q];
-        int margin[BATCH];
-        int all_fail = -1;  // sign bit stays set while every row of the batch fails
-#pragma unroll
-        for (int q = 0; q < BATCH; ++q) {
-          margin[q] = margin_of(cur[q], sr);
-          all_fail &= margin[q];
-        }
-        if (__any(all_fail >= 0)) {  // rare
-          uint32_t cand = 0;  // per lane: bit q = row q may reach the threshold
-#pragma unroll
-          for (int q = 0; q < BATCH; ++q) cand |= margin[q] >= 0 ? (1u << q) : 0u;
-          for (int q = 0; q < BATCH; ++q) {  // ONE copy of the matrix body (I-cache footprint)
-            if (__any((cand >> q) & 1u)) {
-              // second stage: an independent signature must agree before the matrix is paid for
-              if (second_stage(i + q)) exact_row(i + q);
-            }
+        for (int q = 0; q < BATCH; ++q) cand |= margin[q] >= 0 ? (1u << q) : 0u;
+        for (int q = 0; q < BATCH; ++q) {  // ONE copy of the matrix body (I-cache footprint)
+          if (__any((cand >> q) & 1u)) {
+            // second stage: an independent signature must agree before the matrix is paid for
+            if (second_stage(i + q)) exact_row(i + q);
           }
         }
+      }
+    };
+    auto load_batch = [&](uint64_t (&sg)[BATCH], int i) {
 #pragma unroll
-        for (int q = 0; q < BATCH; ++q) cur[q] = nxt[q];
+      for (int q = 0; q < BATCH; ++q) sg[q] = lsig[i + q];  // one s_load_dwordx16
+    };
+    int i = a;
+    if (i + BATCH <= b) {
+      // software pipeline over two register sets: the signature words of the next batch are in flight
+      // while this one is tested, and no set is copied (8 s_mov_b64 per batch on the shared scalar unit)
+      uint64_t s0[BATCH], s1[BATCH];
+      load_batch(s0, i);
+      while (true) {
+        const bool more1 = i + 2 * BATCH <= b;
+        load_batch(s1, more1 ? i + BATCH : i);  // the last batch re-reads itself
+        test_batch(s0, i);
+        i += BATCH;
+        if (!more1) break;
+        const bool more0 = i + 2 * BATCH <= b;
+        load_batch(s0, more0 ? i + BATCH : i);
+        test_batch(s1, i);
+        i += BATCH;
+        if (!more0) break;
       }
     }
     for (; i < b; ++i) {
