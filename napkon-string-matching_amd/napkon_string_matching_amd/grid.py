@@ -147,6 +147,8 @@ def jaccard_levels_grid(
     lib = _lib.load()
     ls, rs = left.struct(), right.struct()
     flags = _lib.FLAG_PRUNE if prune else 0
+    if (left.seg is None) != (right.seg is None) or left.category_mode != right.category_mode:
+        raise ValueError("both sides must be encoded alike: same category_mode and partition (tables.partition_allowed)")
     if left.category_mode is not None:  # the encoder may have rewritten the predicate (partition)
         category_mode = left.category_mode
 
@@ -167,6 +169,8 @@ def indel_levels_grid(
     lib = _lib.load()
     li, ls, ri, rs = left.struct(), left_strings.struct(), right.struct(), right_strings.struct()
     flags = _lib.FLAG_PRUNE if prune else 0
+    if (left.seg is None) != (right.seg is None) or left.category_mode != right.category_mode:
+        raise ValueError("both sides must be encoded alike: same category_mode and partition (tables.partition_allowed)")
     if left.category_mode is not None:  # the encoder may have rewritten the predicate (partition)
         category_mode = left.category_mode
 

@@ -53,6 +53,17 @@ def pick_stride(max_len: int) -> int:
     )
 
 
+def partition_allowed(category_mode: int, *category_masks: Optional[np.ndarray]) -> bool:
+    """Whether BOTH sides of a levels grid can be partitioned by category.  With the "both empty also
+    matches" predicate the empty items become one more category (bit 63), which needs that bit to be
+    free on both sides -- a joint property, so the caller decides once and encodes both sides alike."""
+    if category_mode == _lib.CAT_NONE or any(m is None for m in category_masks):
+        return False
+    if category_mode == _lib.CAT_INTERSECT_OR_BOTH_EMPTY:
+        return not any(len(m) and int(np.asarray(m, dtype=np.uint64).max()) >> EMPTY_CATEGORY_BIT for m in category_masks)
+    return True
+
+
 def signatures(ids: np.ndarray, cnt: np.ndarray, multiplier: np.uint32 = _GOLDEN) -> np.ndarray:
     """Signature word per row (include/nsm_hip.h): 58 hash bits; the top 6 bits hold, in UNARY, the
     number c of ids that collided with an earlier id of the same row, so that with the other side's
@@ -279,11 +290,12 @@ class SetTable:
             # Category partition (see encode_level_strings): an item with k categories becomes k rows,
             # rows are grouped per category; "both empty" becomes one more category of the empty items.
             if mode == _lib.CAT_INTERSECT_OR_BOTH_EMPTY:
-                if n and int(cat.max()) >> EMPTY_CATEGORY_BIT:
-                    partition = False
-                else:
-                    cat[cat == 0] = np.uint64(1) << np.uint64(EMPTY_CATEGORY_BIT)
-                    mode = _lib.CAT_INTERSECT
+                if not partition_allowed(mode, cat):
+                    raise ValueError(
+                        "category bit 63 is in use, so the empty items cannot become a category of their own: "
+                        "encode BOTH sides with partition=False (tables.partition_allowed decides for a pair)")
+                cat[cat == 0] = np.uint64(1) << np.uint64(EMPTY_CATEGORY_BIT)
+                mode = _lib.CAT_INTERSECT
         if mode != _lib.CAT_NONE and partition:
             rows, segs = [], []
             for c in range(64):

@@ -599,8 +599,11 @@ def _levels_grid(plugin, levels_l, levels_r, threshold, cat_l, cat_r, cat_mode=_
         width = tables.pick_width(
             max((len(set(it[-1])) for it in sl if it), default=1), max((len(set(it[-1])) for it in sr if it), default=1)
         )
-        lt = tables.SetTable.from_levels(sl, "left", dev, vocab, width=width, categories=cat_l, category_mode=cat_mode)
-        rt = tables.SetTable.from_levels(sr, "right", dev, vocab, width=width, categories=cat_r, category_mode=cat_mode)
+        part = tables.partition_allowed(cat_mode, cat_l, cat_r)
+        lt = tables.SetTable.from_levels(sl, "left", dev, vocab, width=width, categories=cat_l, category_mode=cat_mode,
+                                         partition=part)
+        rt = tables.SetTable.from_levels(sr, "right", dev, vocab, width=width, categories=cat_r, category_mode=cat_mode,
+                                         partition=part)
         if len(vocab) >= 1 << 25:
             raise NotImplementedError("vocabulary of 2^25 or more distinct tokens")
         return grid.jaccard_levels_grid(lt, rt, threshold, category_mode=cat_mode)
