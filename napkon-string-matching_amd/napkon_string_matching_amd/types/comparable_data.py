@@ -417,6 +417,11 @@ class ComparableData:
                 raise IndexError("single positional indexer is out-of-bounds")  # df.iloc[0] at :465
             cl, cr = list(lf[category_column]), list(rf[category_column])
             cats = _Categories(cl, cr, cl[first[0]], cr[first[1]])
+        elif n_l == 0 or n_r == 0:
+            # the reference's blacklist step indexes the cross join with a list of booleans (:549-552); for
+            # an EMPTY cross join that list is empty, pandas reads it as "no columns", and :223-232 then
+            # fails on the compare column
+            raise KeyError(lp + COMP_COLUMN)
 
         def survives(i: int, j: int) -> bool:
             return (i, j) not in banned and (cats is None or cats.match(i, j))

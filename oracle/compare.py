@@ -103,14 +103,14 @@ def existing_mapping_ids(identifiers: Sequence[str], group: str, mapping: Mappin
 
 def whitelist_removals(
     left_ids: Sequence[str], right_ids: Sequence[str], left_name: str, right_name: str, whitelist: MappingDict
-) -> Tuple[List[str], List[str]]:
-    """comparable_data.py:493-520 -- identifiers to drop on each side; the whole step is
-    skipped (nothing removed) on KeyError (:500-504)."""
+) -> Optional[Tuple[List[str], List[str]]]:
+    """comparable_data.py:493-520 -- identifiers to drop on each side; None when the whole step is
+    skipped on KeyError (:500-504)."""
     try:
         ids_l = existing_mapping_ids(left_ids, left_name, whitelist)
         ids_r = existing_mapping_ids(right_ids, right_name, whitelist)
     except KeyError:
-        return [], []
+        return None
     used = set(ids_l) & set(ids_r)
     kept = {key: entry for key, entry in whitelist.items() if key in used}  # mapping.py:200-203
     drop_l: List[str] = []
@@ -164,24 +164,32 @@ def gen_comparable(
     left = left.dropna(subset=[compare_column])  # :152
     right = right.dropna(subset=[compare_column])  # :153
 
-    drop_l, drop_r = whitelist_removals(  # :162-168
+    removals = whitelist_removals(  # :162-168
         list(left["Identifier"]), list(right["Identifier"]), left_name, right_name, whitelist
     )
-    left = left[[ident not in drop_l for ident in left["Identifier"]]]  # :267-273
-    right = right[[ident not in drop_r for ident in right["Identifier"]]]
+    if removals is not None:  # None: the step was skipped as a whole (KeyError, :500-504)
+        drop_l, drop_r = removals
+        # :267-273 index the frame with a list of booleans; for a frame WITHOUT ROWS that list is empty,
+        # pandas reads `frame[[]]` as "no columns", and the compare column is gone (KeyError below)
+        left = left[[ident not in drop_l for ident in left["Identifier"]]]
+        right = right[[ident not in drop_r for ident in right["Identifier"]]]
 
     lp, rp = left_name.title(), right_name.title()  # :186-187
 
-    def side(frame: pd.DataFrame, prefix: str):
+    # :176-184 read the columns left-compare, right-compare, left-Term, right-Term in that order
+    values = [list(left[compare_column]), list(right[compare_column])]  # KeyError on a column-less frame
+    terms = [list(left["Term"]), list(right["Term"])]
+
+    def side(frame: pd.DataFrame, prefix: str, compare_values, term_values):
         rows = []
-        for _, row in frame.iterrows():
+        for (_, row), value, term in zip(frame.iterrows(), compare_values, term_values):
             rec = {prefix + col: row[col] for col in frame.columns}
-            rec[prefix + "Compare"] = gen_comp_value(row[compare_column], **tok)  # :176-177
-            rec[prefix + "Argument"] = ":".join(flatten_list(row["Term"]))  # :179-184
+            rec[prefix + "Compare"] = gen_comp_value(value, **tok)  # :176-177
+            rec[prefix + "Argument"] = ":".join(flatten_list(term))  # :179-184
             rows.append(rec)
         return rows
 
-    rows_l, rows_r = side(left, lp), side(right, rp)
+    rows_l, rows_r = side(left, lp, values[0], terms[0]), side(right, rp, values[1], terms[1])
     n_right = len(rows_r)
 
     banned = blacklist_pairs(left_name, right_name, blacklist)  # :534
@@ -195,6 +203,9 @@ def gen_comparable(
                 continue
             grid.append((i * n_right + j, a, b))
 
+    # :191-206 -- the blacklist step also indexes with a list of booleans: an EMPTY cross join comes out
+    # of it without columns (a cross join emptied by the blacklist keeps them)
+    columnless = not rows_l or not rows_r
     if filter_categories:  # :209-218
         if not grid:
             raise IndexError("single positional indexer is out-of-bounds")  # df.iloc[0], :465
@@ -207,6 +218,8 @@ def gen_comparable(
     def kept(frame: pd.DataFrame, prefix: str) -> List[str]:
         return [prefix + c for c in list(frame.columns) + ["Compare", "Argument"] if c in OUTPUT_COLUMNS]
 
+    if columnless:
+        raise KeyError(lp + "Compare")  # :223-232 reads the compare columns of the column-less frame
     keep_cols = kept(left, lp) + kept(right, rp)
     out_index, out_rows = [], []
     for label, a, b in grid:
