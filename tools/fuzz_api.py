@@ -50,8 +50,16 @@ def main():
             except Exception as exc:  # the reference's own per-pair errors are part of the contract
                 return None, exc
 
-        want, want_exc = run(lambda: oc.gen_comparable(left.copy(), right.copy(), wl, bl, **kw))
-        got, got_exc = run(lambda: Questionnaire(left.copy()).gen_comparable(Questionnaire(right.copy()), wl, bl, **kw).dataframe())
+        if rnd % 3 == 0:  # every third round through compare(): cache threshold, score filter, descending order
+            ckw = dict(kw, cache_threshold=random.Random(rnd).choice([None, 0.05, 0.3, 0.6]))
+            column = ckw.pop("compare_column")
+            want, want_exc = run(lambda: oc.compare(left.copy(), right.copy(), wl, bl, column, **ckw))
+            got, got_exc = run(lambda: Questionnaire(left.copy()).compare(
+                Questionnaire(right.copy()), wl, bl, column, cached=False, **ckw).dataframe())
+        else:
+            want, want_exc = run(lambda: oc.gen_comparable(left.copy(), right.copy(), wl, bl, **kw))
+            got, got_exc = run(lambda: Questionnaire(left.copy()).gen_comparable(
+                Questionnaire(right.copy()), wl, bl, **kw).dataframe())
         problem = None
         if (want_exc is None) != (got_exc is None) or (want_exc is not None and type(want_exc) is not type(got_exc)):
             problem = f"oracle: {want_exc!r}  /  package: {got_exc!r}"
