@@ -39,8 +39,12 @@ def main():
     t_end = time.time() + args.seconds
     rnd = args.seed
     stats = {"rounds": 0, "frames": 0, "raised": {}, "rows": 0}
+    next_report = time.time() + 60.0
     while time.time() < t_end:
         rnd += 1
+        if time.time() >= next_report:  # a long silent GPU job is taken to be hung
+            print(json.dumps({"progress": stats, "round_seed": rnd}), flush=True)
+            next_report += 60.0
         left, right, wl, bl, kw, kinds = rf.case(rnd)
         stats["rounds"] += 1
 

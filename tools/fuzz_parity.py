@@ -73,8 +73,12 @@ def main():
     def rand_string(rng, alphabet, lo, hi):
         return "".join(rng.choice(alphabet) for _ in range(rng.randint(lo, hi))).strip()
 
+    next_report = time.time() + 60.0
     while time.time() < t_end:
         rnd += 1
+        if time.time() >= next_report:  # a long silent GPU job is taken to be hung
+            print(json.dumps({"progress": counts, "round_seed": rnd}), flush=True)
+            next_report += 60.0
         rng = random.Random(rnd)
         family = rng.choice(["jaccard_raw", "indel_raw", "jaccard_levels", "indel_levels"])
         counts[family] = counts.get(family, 0) + 1
