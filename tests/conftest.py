@@ -5,7 +5,6 @@
 * builds the C oracle on demand (test infrastructure; never used by the product).
 """
 import json
-import os
 import sys
 from pathlib import Path
 

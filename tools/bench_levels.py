@@ -31,7 +31,6 @@ def main():
                     help="words per entry; 6 makes the level strings 40..170 code units (multi-word Indel kernels)")
     args = ap.parse_args()
 
-    import numpy as np
     import torch
 
     from napkon_string_matching_amd import _lib, grid, synthetic, tables

@@ -27,8 +27,6 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
 
-    import numpy as np
-    import pandas as pd
 
     from napkon_string_matching_amd.types.questionnaire import Questionnaire
     from oracle import compare as oc
