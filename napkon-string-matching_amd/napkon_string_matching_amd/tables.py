@@ -103,6 +103,42 @@ class Vocabulary:
         return len(self._ids)
 
 
+class LevelPool:
+    """Encoded levels of items that take part in SEVERAL grids (k cohorts: every item is in k - 1 of them):
+    one shared vocabulary, every item encoded once -- by the identity of its level list -- into pooled
+    arrays of the widest layout (64 ids, 64 levels); a grid gathers its rows from the pool."""
+
+    def __init__(self) -> None:
+        self.vocab = Vocabulary()
+        self._slot: Dict[int, int] = {}
+        self._keep: List[object] = []  # keeps the level lists alive, so their ids cannot be reused
+        self._ids = np.zeros((0, WIDTHS[-1]), dtype=np.int32)
+        self._plen = np.zeros((0, MAX_LEVELS), dtype=np.uint8)
+        self._nlev = np.zeros(0, dtype=np.int32)
+
+    def rows(self, items: Sequence[Sequence[Iterable[Hashable]]]):
+        """(ids [n][64], plen [n][64], nlev [n]) of ``items``; unseen items are encoded and pooled."""
+        return self.rows_keyed(items, None)
+
+    def rows_keyed(self, keys: Sequence[object], convert=None):
+        """As ``rows``, with the pool keyed by the identity of ``keys[k]``; the levels to encode for a NEW key
+        are ``convert(key)`` (the caller's token-list view of the item), only evaluated for new keys."""
+        slot = self._slot
+        fresh = list({id(k): k for k in keys if id(k) not in slot}.values())
+        if fresh:
+            todo = fresh if convert is None else [convert(k) for k in fresh]
+            ids, plen, nlev, _, _ = SetTable.encode_levels(todo, self.vocab, width=WIDTHS[-1], max_levels=MAX_LEVELS)
+            base = len(self._keep)
+            for k, it in enumerate(fresh):
+                slot[id(it)] = base + k
+            self._keep.extend(fresh)
+            self._ids = np.concatenate([self._ids, ids])
+            self._plen = np.concatenate([self._plen, plen])
+            self._nlev = np.concatenate([self._nlev, nlev])
+        idx = np.fromiter((slot[id(k)] for k in keys), dtype=np.int64, count=len(keys))
+        return self._ids[idx], self._plen[idx], self._nlev[idx]
+
+
 @dataclass
 class SetTable:
     ids: torch.Tensor
@@ -189,6 +225,16 @@ class SetTable:
     ) -> "SetTable":
         """Levels table.  ``items[k]`` is the level list of item k (``gen_comp_value`` output,
         types/comparable_data.py:283-285): level l must contain level l-1 (suffix nesting)."""
+        ids, plen, nlev, max_levels, width = cls.encode_levels(items, vocab, width)
+        cnt = (ids >= 0).sum(axis=1).astype(np.int32)
+        return cls._finish(ids, cnt, side, device, width, None, nlev=nlev, plen=plen, cat=categories,
+                           max_levels=max_levels, category_mode=category_mode, partition=partition)
+
+    @staticmethod
+    def encode_levels(items: Sequence[Sequence[Iterable[Hashable]]], vocab: Vocabulary, width: Optional[int] = None,
+                      max_levels: Optional[int] = None):
+        """The per-item part of ``from_levels``: (ids [n][width], plen [n][max_levels] uint8, nlev [n] int32,
+        max_levels, width) in suffix-nested layout; raises for items that are not nested."""
         n = len(items)
         nlev = np.fromiter((len(levels) for levels in items), dtype=np.int64, count=n)
         if n and int(nlev.max()) > MAX_LEVELS:
@@ -216,13 +262,15 @@ class SetTable:
         item_start = np.zeros(n, dtype=np.int64)
         np.cumsum(per_item[:-1], out=item_start[1:])
         rank = np.arange(len(first), dtype=np.int64) - item_start[u_item]
+        if n and int(per_item.max()) > WIDTHS[-1]:
+            pick_width(int(per_item.max()))  # raises: more distinct tokens than the kernels hold
         width = width or pick_width(int(per_item.max()) if n else 1)
         if n and int(per_item.max()) > width:
             k = int(np.argmax(per_item > width))
             raise ValueError(f"item {k} has {int(per_item[k])} ids > width {width}")
         ids = np.full((n, width), -1, dtype=np.int32)
         ids[u_item, rank] = u_id
-        max_levels = max(4, -(-(int(nlev.max()) if n else 1) // 4) * 4)
+        max_levels = max_levels or max(4, -(-(int(nlev.max()) if n else 1) // 4) * 4)
         # plen[k][l] = ids first seen at a level <= l; levels past the item's last repeat its last value
         new_at = np.zeros((n, max_levels), dtype=np.int64)
         np.add.at(new_at, (u_item, u_level), 1)
@@ -239,11 +287,7 @@ class SetTable:
             raise NotImplementedError(
                 f"item {k}: level {lv} does not contain level {lv - 1}; only suffix-nested levels (what "
                 "gen_comp_value produces) are supported on the GPU")
-        plen = plen_full.astype(np.uint8)
-        nlev = nlev.astype(np.int32)
-        cnt = (ids >= 0).sum(axis=1).astype(np.int32)
-        return cls._finish(ids, cnt, side, device, width, None, nlev=nlev, plen=plen, cat=categories,
-                           max_levels=max_levels, category_mode=category_mode, partition=partition)
+        return ids, plen_full.astype(np.uint8), nlev.astype(np.int32), max_levels, width
 
     @classmethod
     def from_nested_arrays(

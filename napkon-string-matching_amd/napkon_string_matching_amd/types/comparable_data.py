@@ -140,7 +140,20 @@ class _Categories:
             raise TypeError("unhashable type: 'list'")
         self.mode = _lib.CAT_INTERSECT_OR_BOTH_EMPTY if (l_list and r_list) else _lib.CAT_INTERSECT
         self.scalar_scalar = not l_list and not r_list
-        bits: Dict[object, int] = {}
+        # inside item_memo() the label -> bit assignment is shared by the run's grids, which makes the
+        # per-cell result reusable (a cohort's cells are looked at once per grid it takes part in)
+        memo = ComparableData._item_memo
+        bits: Dict[object, int] = {} if memo is None else memo.setdefault(("category bits",), {})
+
+        def mask_of(value, as_list: bool) -> Tuple[int, frozenset]:
+            if memo is None:
+                return mask(value, as_list)
+            key = ("category", as_list, id(value))
+            got = memo.get(key)
+            if got is None or got[0] is not value:
+                got = (value, mask(value, as_list))
+                memo[key] = got
+            return got[1]
 
         def mask(value, as_list: bool) -> Tuple[int, frozenset]:
             labels = value if as_list else [value]
@@ -157,8 +170,8 @@ class _Categories:
                 m |= 1 << bits.setdefault(lab, len(bits))
             return m, frozenset(keys)
 
-        lm = [mask(v, l_list) for v in left]
-        rm = [mask(v, r_list) for v in right]
+        lm = [mask_of(v, l_list) for v in left]
+        rm = [mask_of(v, r_list) for v in right]
         self.left_sets = [s for _, s in lm]
         self.right_sets = [s for _, s in rm]
         self.on_device = len(bits) <= 64
@@ -598,17 +611,32 @@ def _levels_grid(plugin, levels_l, levels_r, threshold, cat_l, cat_r, cat_mode=_
         raise _lib.NsmLibraryError("the match loop runs on an MI355X (HIP device); there is no CPU fallback")
     dev = torch.device("cuda", torch.cuda.current_device())
     if plugin.kind == "sets":
-        vocab = tables.Vocabulary()
-        as_sets = lambda items: [[lv if isinstance(lv, list) else lv.split() for lv in it] for it in items]
-        sl, sr = as_sets(levels_l), as_sets(levels_r)
-        width = tables.pick_width(
-            max((len(set(it[-1])) for it in sl if it), default=1), max((len(set(it[-1])) for it in sr if it), default=1)
-        )
+        as_set_levels = lambda it: [lv if isinstance(lv, list) else lv.split() for lv in it]
         part = tables.partition_allowed(cat_mode, cat_l, cat_r)
-        lt = tables.SetTable.from_levels(sl, "left", dev, vocab, width=width, categories=cat_l, category_mode=cat_mode,
-                                         partition=part)
-        rt = tables.SetTable.from_levels(sr, "right", dev, vocab, width=width, categories=cat_r, category_mode=cat_mode,
-                                         partition=part)
+        memo = ComparableData._item_memo
+        if memo is not None:
+            # inside item_memo(): one vocabulary for the whole run, every item encoded once (tables.LevelPool,
+            # keyed by the identity of the memoised level lists)
+            pool = memo.setdefault(("level pool",), tables.LevelPool())
+            vocab = pool.vocab
+            rows = [pool.rows_keyed(levels, as_set_levels) for levels in (levels_l, levels_r)]
+            width = tables.pick_width(*(int((ids >= 0).sum(axis=1).max(initial=1)) for ids, _, _ in rows))
+            sides = []
+            for (ids, plen, nlev), side, cat in zip(rows, ("left", "right"), (cat_l, cat_r)):
+                deepest = max(4, -(-(int(nlev.max()) if len(nlev) else 1) // 4) * 4)
+                sides.append(tables.SetTable.from_nested_arrays(ids, plen[:, :deepest], nlev, side, dev, categories=cat,
+                                                                width=width, category_mode=cat_mode, partition=part))
+            lt, rt = sides
+        else:
+            vocab = tables.Vocabulary()
+            sl, sr = [as_set_levels(it) for it in levels_l], [as_set_levels(it) for it in levels_r]
+            width = tables.pick_width(
+                max((len(set(it[-1])) for it in sl if it), default=1), max((len(set(it[-1])) for it in sr if it), default=1)
+            )
+            lt = tables.SetTable.from_levels(sl, "left", dev, vocab, width=width, categories=cat_l, category_mode=cat_mode,
+                                             partition=part)
+            rt = tables.SetTable.from_levels(sr, "right", dev, vocab, width=width, categories=cat_r,
+                                             category_mode=cat_mode, partition=part)
         if len(vocab) >= 1 << 25:
             raise NotImplementedError("vocabulary of 2^25 or more distinct tokens")
         return grid.jaccard_levels_grid(lt, rt, threshold, category_mode=cat_mode)

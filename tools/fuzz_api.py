@@ -52,7 +52,20 @@ def main():
             except Exception as exc:  # the reference's own per-pair errors are part of the contract
                 return None, exc
 
-        if rnd % 3 == 0:  # every third round through compare(): cache threshold, score filter, descending order
+        if rnd % 4 == 1:  # inside item_memo(): pooled level encoding, shared vocabulary and category bits
+            from napkon_string_matching_amd.types.comparable_data import ComparableData
+
+            def pooled():
+                ql, qr = Questionnaire(left.copy()), Questionnaire(right.copy())
+                with ComparableData.item_memo():
+                    first = ql.gen_comparable(qr, wl, bl, **kw).dataframe()
+                    again = ql.gen_comparable(qr, wl, bl, **kw).dataframe()  # every item now comes from the pool
+                assert rf.frames_differ(again, first, 0.0) is None
+                return first
+
+            want, want_exc = run(lambda: oc.gen_comparable(left.copy(), right.copy(), wl, bl, **kw))
+            got, got_exc = run(pooled)
+        elif rnd % 3 == 0:  # every third round through compare(): cache threshold, score filter, descending order
             ckw = dict(kw, cache_threshold=random.Random(rnd).choice([None, 0.05, 0.3, 0.6]))
             column = ckw.pop("compare_column")
             want, want_exc = run(lambda: oc.compare(left.copy(), right.copy(), wl, bl, column, **ckw))
