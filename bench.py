@@ -409,8 +409,26 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            from datetime import timedelta
+
+            try:  # RCCL; one tiny collective up front so that a broken transport shows here, not mid-run
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device,
+                                        timeout=timedelta(seconds=300))
+                probe = torch.ones(1, device=device)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize(device)
+                assert int(probe.item()) == world
+            except Exception as exc:  # keep the run alive: the same exchange staged through host memory
+                print(f"[bench] RCCL unavailable ({type(exc).__name__}: {exc}); falling back to the gloo-staged exchange",
+                      file=sys.stderr)
+                try:
+                    dist.destroy_process_group()
+                except Exception:
+                    pass
+                args.dist_backend = "gloo"
+                dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
@@ -556,6 +574,7 @@ def main():
             "pairs_per_step": pairs_per_step,
             "hits_per_rank": n_hits,
             "sharding": f"left rows block-sharded over {world} rank(s), right replicated, hits all-gathered",
+            "exchange": None if world == 1 else ("rccl all-gather" if args.dist_backend == "nccl" else "gloo, staged through host memory"),
             "exact_prune": True,
             "encode_and_h2d_seconds_once": round(work.encode_h2d_seconds, 4),
         },
