@@ -110,7 +110,7 @@ typedef struct nsm_str_table {
   const int32_t* len_start;
   const uint8_t* hist;
   int32_t n;
-  int32_t stride;   /* 64, 128 or 256 code units per row (1, 2 or 4 words of the bit-parallel LCS),
+  int32_t stride;   /* 64, 128, 256 or 512 code units per row (1, 2, 4 or 8 words of the bit-parallel LCS),
                        the same on both sides of a grid; anything else: NSM_E_UNSUPPORTED */
   int32_t alphabet; /* number of distinct code units, <= 255 */
 } nsm_str_table;

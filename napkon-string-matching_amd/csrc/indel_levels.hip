@@ -76,7 +76,7 @@ __device__ __forceinline__ T lev_lds_load(uint32_t addr) {
 #endif
 // left rows scored together, step by step; the 4-word kernel already spends 18 KB of LDS per wave on
 // masks and text image, 4 rows (2 KB of scores) keep 8 waves per CU
-constexpr int lev_batch(int K) { return K == 4 ? NSM_LEV_BATCH / 2 : NSM_LEV_BATCH; }
+constexpr int lev_batch(int K) { return K >= 4 ? NSM_LEV_BATCH / 2 : NSM_LEV_BATCH; }
 
 template <int K>
 __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
@@ -297,8 +297,8 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
     return NSM_E_BADARG;
   }
   const int stride = left_strings->stride;
-  if (stride != right_strings->stride || (stride != 64 && stride != 128 && stride != 256)) {
-    set_error("nsm_indel_levels_grid: stride %d/%d unsupported (both sides 64, 128 or 256 code units)",
+  if (stride != right_strings->stride || (stride != 64 && stride != 128 && stride != 256 && stride != 512)) {
+    set_error("nsm_indel_levels_grid: stride %d/%d unsupported (both sides 64, 128, 256 or 512 code units)",
               left_strings->stride, right_strings->stride);
     return NSM_E_UNSUPPORTED;
   }
@@ -362,7 +362,8 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
                      right_strings->codes, right_strings->len, hits, hit_count, p)
   if (K == 1) NSM_LAUNCH_LEVELS(1);
   else if (K == 2) NSM_LAUNCH_LEVELS(2);
-  else NSM_LAUNCH_LEVELS(4);
+  else if (K == 4) NSM_LAUNCH_LEVELS(4);
+  else NSM_LAUNCH_LEVELS(8);
 #undef NSM_LAUNCH_LEVELS
   return hip_status(hipGetLastError(), "indel_levels_kernel launch");
 }

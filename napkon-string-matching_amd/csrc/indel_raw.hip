@@ -266,8 +266,8 @@ extern "C" int nsm_indel_raw_grid(const nsm_str_table* left, const nsm_str_table
     set_error("nsm_indel_raw_grid: null argument");
     return NSM_E_BADARG;
   }
-  if (left->stride != right->stride || (left->stride != 64 && left->stride != 128 && left->stride != 256)) {
-    set_error("nsm_indel_raw_grid: stride %d/%d unsupported (both sides 64, 128 or 256 code units)",
+  if (left->stride != right->stride || (left->stride != 64 && left->stride != 128 && left->stride != 256 && left->stride != 512)) {
+    set_error("nsm_indel_raw_grid: stride %d/%d unsupported (both sides 64, 128, 256 or 512 code units)",
               left->stride, right->stride);
     return NSM_E_UNSUPPORTED;
   }

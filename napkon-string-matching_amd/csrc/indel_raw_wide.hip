@@ -1,4 +1,4 @@
-// RAW Indel-ratio grid for strings of 65..256 code units (stride 128 / 256).  Same structure as
+// RAW Indel-ratio grid for strings of 65..512 code units (stride 128 / 256 / 512).  Same structure as
 // indel_raw.hip (length classes, exact length + histogram prunes, integer threshold test against a
 // launcher-computed table), with the multi-word LCS of indel_wide.hpp.
 #include "indel_wide.hpp"
@@ -12,7 +12,7 @@ struct IndelWideParams {
   int32_t pm_stride;
   int32_t zero_need;  // 0 when a 0.0 score reaches the threshold, else kNeverWide
   unsigned long long cap;
-  uint16_t lcsmin[520];  // indexed by la + lb (both >= 1), up to 512
+  uint16_t lcsmin[1032];  // indexed by la + lb (both >= 1), up to 1024
 };
 
 __device__ __forceinline__ double indel_score_wide(int la, int lb, int lcs) {
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(kBlock) void indel_raw_wide_kernel(
   constexpr int kMaxLen = kWave * K;
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_mem[];
   // layout: [wave][pm_stride * K] masks | [wave][16 K][64] text dwords | lcsmin
-  const int waves = blockDim.x >> 6;  // 4 (K = 2) or 2 (K = 4): keeps the block under 64 KiB of LDS
+  const int waves = blockDim.x >> 6;  // 4 (K = 2), 2 (K = 4) or 1 (K = 8): keeps the block under 64 KiB of LDS
   unsigned long long* pm_all = s_mem;
   uint32_t* text_all = reinterpret_cast<uint32_t*>(pm_all + waves * p.pm_stride * K);
   uint16_t* s_lcsmin = reinterpret_cast<uint16_t*>(text_all + waves * 16 * K * kWave);
@@ -115,7 +115,7 @@ static int launch_wide(const nsm_str_table* left, const nsm_str_table* right, do
   p.n_left = left->n; p.n_right = right->n; p.cap = capacity;
   p.pm_stride = ((left->alphabet + 1) + 63) / 64 * 64;
   p.zero_need = (0.0 >= threshold) ? 0 : kNeverWide;
-  for (int s = 0; s < 520; ++s) {
+  for (int s = 0; s < 1032; ++s) {
     p.lcsmin[s] = kNeverWide;
     if (s < 2 || s > 2 * kMaxLen) continue;
     for (int lcs = 0; 2 * lcs <= s; ++lcs) {
@@ -132,7 +132,7 @@ static int launch_wide(const nsm_str_table* left, const nsm_str_table* right, do
   if (rows < 64) rows = 64;
   if (rows > 4096) rows = 4096;
   p.rows_per_chunk = static_cast<int>(rows);
-  constexpr int kWaves = K == 2 ? 4 : 2;
+  constexpr int kWaves = K == 2 ? 4 : (K == 4 ? 2 : 1);
   dim3 grid((n_tiles + kWaves - 1) / kWaves, (left->n + p.rows_per_chunk - 1) / p.rows_per_chunk);
   if (grid.y > 65535) {
     p.rows_per_chunk = (left->n + 65534) / 65535;
@@ -151,12 +151,14 @@ static int launch_wide(const nsm_str_table* left, const nsm_str_table* right, do
   return hip_status(hipGetLastError(), "indel_raw_wide_kernel launch");
 }
 
-// called by nsm_indel_raw_grid for stride 128 / 256
+// called by nsm_indel_raw_grid for stride 128 / 256 / 512
 int indel_raw_wide(const nsm_str_table* left, const nsm_str_table* right, double threshold, uint32_t flags,
                    nsm_hit* hits, uint64_t capacity, unsigned long long* hit_count, hipStream_t stream) {
   if (left->stride == 128)
     return launch_wide<2>(left, right, threshold, flags, hits, capacity, hit_count, stream);
-  return launch_wide<4>(left, right, threshold, flags, hits, capacity, hit_count, stream);
+  if (left->stride == 256)
+    return launch_wide<4>(left, right, threshold, flags, hits, capacity, hit_count, stream);
+  return launch_wide<8>(left, right, threshold, flags, hits, capacity, hit_count, stream);
 }
 
 }  // namespace nsm

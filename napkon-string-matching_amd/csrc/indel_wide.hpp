@@ -1,4 +1,4 @@
-// Multi-word bit-parallel LCS for strings of 65..256 code units (K = 2 or 4 words of 64 bits).
+// Multi-word bit-parallel LCS for strings of 65..512 code units (K = 2, 4 or 8 words of 64 bits).
 // Shared by the RAW and the levels-mode Indel grids.  Real NAPKON `Term` strings (header + question
 // + parameter, reference: napkon_string_matching/types/questionnaire.py:59-68) routinely exceed 64
 // code units, so this is the path the reference's default configuration (compare_column: Term,
@@ -77,8 +77,14 @@ __device__ __forceinline__ void add_chain(const unsigned long long (&v)[W], cons
         : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5])
         : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(b[0]), "v"(b[1]), "v"(b[2]),
           "v"(b[3]), "v"(b[4]), "v"(b[5]) : "vcc");
+  } else if constexpr (W > 4) {
+    // 5..8 words (strings beyond 256 code units, rare): the compiler's carry chain
+    unsigned long long carry = 0;
+#pragma unroll
+    for (int k = 0; k < W; ++k) t[k] = __builtin_addcll(v[k], u[k], carry, &carry);
+    return;
   } else {
-    static_assert(W == 4, "1..4 words");
+    static_assert(W == 4, "1..8 words");
     asm("v_add_co_u32 %0, vcc, %8, %16\n\tv_addc_co_u32 %1, vcc, %9, %17, vcc\n\t"
         "v_addc_co_u32 %2, vcc, %10, %18, vcc\n\tv_addc_co_u32 %3, vcc, %11, %19, vcc\n\t"
         "v_addc_co_u32 %4, vcc, %12, %20, vcc\n\tv_addc_co_u32 %5, vcc, %13, %21, vcc\n\t"
@@ -140,6 +146,8 @@ __device__ __forceinline__ int wide_lcs(const unsigned long long* pm, const uint
   if (words <= 1) return wide_lcs_words<K, 1, EARLY>(pm, text, nchars, lane, lb, need);
   if (K >= 2 && words == 2) return wide_lcs_words<K, (K >= 2 ? 2 : 1), EARLY>(pm, text, nchars, lane, lb, need);
   if (K >= 4 && words == 3) return wide_lcs_words<K, (K >= 4 ? 3 : 1), EARLY>(pm, text, nchars, lane, lb, need);
+  if (K >= 4 && words == 4) return wide_lcs_words<K, (K >= 4 ? 4 : 1), EARLY>(pm, text, nchars, lane, lb, need);
+  if (K >= 8 && words <= 6) return wide_lcs_words<K, (K >= 8 ? 6 : 1), EARLY>(pm, text, nchars, lane, lb, need);
   return wide_lcs_words<K, K, EARLY>(pm, text, nchars, lane, lb, need);
 }
 

@@ -26,7 +26,7 @@ import torch
 from . import _lib
 
 WIDTHS = (16, 32, 64)
-STRIDES = (64, 128, 256)  # code units per string row: 1, 2 or 4 words of the bit-parallel LCS
+STRIDES = (64, 128, 256, 512)  # code units per string row: 1, 2, 4 or 8 words of the bit-parallel LCS
 MAX_LEVELS = 64
 LEFT_PAD, RIGHT_PAD = -1, -2
 EMPTY_CATEGORY_BIT = 63  # stands for "no category at all" when empty-vs-empty counts as a match
@@ -49,7 +49,7 @@ def pick_stride(max_len: int) -> int:
         if max_len <= stride:
             return stride
     raise NotImplementedError(
-        f"a string has {max_len} code units; the Indel kernels support up to {STRIDES[-1]} (4 words of 64 bits)"
+        f"a string has {max_len} code units; the Indel kernels support up to {STRIDES[-1]} (8 words of 64 bits)"
     )
 
 
@@ -476,7 +476,7 @@ class StrTable:
         cls, codes: np.ndarray, lengths: np.ndarray, alphabet: int, device, orig: Optional[np.ndarray] = None,
         sort: bool = True,
     ) -> "StrTable":
-        """From uint8 codes [n][stride], stride in {64, 128, 256} (entries at positions >= len are
+        """From uint8 codes [n][stride], stride in {64, 128, 256, 512} (entries at positions >= len are
         ignored) and lengths."""
         codes = np.asarray(codes, dtype=np.uint8)
         lengths = np.asarray(lengths, dtype=np.int32)

@@ -53,7 +53,7 @@ def test_argument_validation_without_gpu():
     cnt = ctypes.c_ulonglong(0)
     rc = lib.nsm_jaccard_raw_grid(a, b, 0.5, 0, None, 0, ctypes.addressof(cnt), None)
     assert rc == 10001 and b"width" in lib.nsm_last_error()
-    s = _lib.NsmStrTable(None, None, None, None, None, 1, 512, 10)  # rows of 512 code units: unsupported
+    s = _lib.NsmStrTable(None, None, None, None, None, 1, 1024, 10)  # rows of 1024 code units: unsupported
     rc = lib.nsm_indel_raw_grid(s, s, 0.5, 0, None, 0, ctypes.addressof(cnt), None)
     assert rc == 10002
     with pytest.raises(NotImplementedError):

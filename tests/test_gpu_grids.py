@@ -188,13 +188,13 @@ def test_indel_known_answers(dev):
     for k, (_, _, want) in enumerate(pairs):
         assert abs(got[(k, k)] - want) <= FUZZY_TOL
     with pytest.raises(NotImplementedError):
-        tables.encode_strings(["x" * 257], ["y"], dev)
+        tables.encode_strings(["x" * 513], ["y"], dev)
 
 
-@pytest.mark.parametrize("hi", [100, 128, 200, 256])
+@pytest.mark.parametrize("hi", [100, 128, 200, 256, 300, 512])
 @pytest.mark.parametrize("prune", [False, True])
 def test_indel_raw_long_strings(dev, hi, prune):
-    """Strings of 65..256 code units: the multi-word LCS (stride 128 / 256)."""
+    """Strings of 65..512 code units: the multi-word LCS (stride 128 / 256 / 512)."""
     from napkon_string_matching_amd import grid, tables
     from oracle import native
 
@@ -207,7 +207,7 @@ def test_indel_raw_long_strings(dev, hi, prune):
     right[6] = left[0][: hi // 2] + "zz" + left[0][hi // 2:hi - 2]
     right[7] = left[1]
     lt, rt = tables.encode_strings(left, right, dev)
-    assert lt.stride == rt.stride == (128 if hi <= 128 else 256)
+    assert lt.stride == rt.stride == (128 if hi <= 128 else 256 if hi <= 256 else 512)
     cp = lambda ss: native.csr([[ord(c) for c in s] for s in ss])
     for thr in (0.0, 0.4, 0.6, 0.9):
         want = native.indel_raw(cp(left), cp(right), thr, cap=1 << 16)
@@ -334,7 +334,7 @@ def test_indel_levels_random(dev, max_levels):
             _same_hits(got, want)
 
 
-@pytest.mark.parametrize("hi", [90, 230])
+@pytest.mark.parametrize("hi", [90, 230, 480])
 def test_indel_levels_long_strings(dev, hi):
     from napkon_string_matching_amd import _lib, grid, tables
     from oracle import native

@@ -105,7 +105,7 @@ def main():
             check(grid.jaccard_raw_grid(lt, rt, thr, prune=prune, capacity=rng.choice([64, 4096, 1 << 16])), want,
                   f"jaccard_raw W={width} kmax={kmax} vocab={vocab} thr={thr} prune={prune} {n}x{m}")
         elif family == "indel_raw":
-            hi = rng.choice([8, 30, 64, 64, 100, 128, 200, 256])
+            hi = rng.choice([8, 30, 64, 64, 100, 128, 200, 256, 400, 512])
             alphabet = rng.choice(["ab", "abcdefgh ", "abcdefghijklmnopqrstuvwxyz0123456789 ", "".join(chr(0x100 + k) for k in range(150))])
             n, m = min(n, 200), min(m, 300)
             left = [rand_string(rng, alphabet, 0 if rng.random() < 0.2 else 1, hi) for _ in range(n)]
@@ -161,7 +161,7 @@ def main():
             else:
                 n, m = min(n, 120), min(m, 200)
                 lcat, rcat = lcat[:n], rcat[:m]
-                hi = rng.choice([10, 40, 64, 64, 120, 250])
+                hi = rng.choice([10, 40, 64, 64, 120, 250, 500])
                 alphabet = rng.choice(["abc ", "abcdefghij klm", "abcdefghijklmnopqrstuvwxyz0123456789 "])
                 max_levels = rng.choice([1, 2, 4, 4, 7])
                 item = lambda: [rand_string(rng, alphabet, 0, hi) for _ in range(rng.randint(1, max_levels))]
