@@ -120,8 +120,9 @@ def test_gen_comparable_against_oracle(golden, score_func, column, thr):
         assert list(got["MatchScore"]) == list(want["MatchScore"])
 
 
+@pytest.mark.parametrize("n_labels", [64, 70])
 @pytest.mark.parametrize("score_func", ["intersection_vs_union", "fuzzy_match"])
-def test_sixty_four_categories(golden, score_func):
+def test_sixty_four_categories(golden, score_func, n_labels):
     """64 distinct category labels fill the mask; with list categories the empty-vs-empty rule then has
     no spare bit to ride on, and only one side may use the last label: the partition decision is joint."""
     from napkon_string_matching_amd.types.questionnaire import Questionnaire
@@ -129,10 +130,10 @@ def test_sixty_four_categories(golden, score_func):
 
     case = golden("pair_grids.json")["rand_40x30_categories"]
     left, right = pd.DataFrame(case["left"]), pd.DataFrame(case["right"])
-    labels = [f"c{k}" for k in range(64)]
+    labels = [f"c{k}" for k in range(n_labels)]  # 70: more labels than mask bits, the predicate moves to the host
     left["Category"] = [[] if k % 7 == 0 else [labels[(3 * k) % 63], labels[(5 * k + 1) % 63]] for k in range(len(left))]
     right["Category"] = [[] if k % 5 == 0 else [labels[(3 * k + 6) % 63]] for k in range(len(right))]
-    left.at[left.index[1], "Category"] = labels          # all 64 labels, the last one only on this side
+    left.at[left.index[1], "Category"] = labels          # every label, the last ones only on this side
     kw = dict(score_func=score_func, compare_column="Tokens", left_name="hap", right_name="suep",
               filter_categories=True, score_threshold=0.15)
     want = oc.gen_comparable(left, right, {}, {}, **kw)
