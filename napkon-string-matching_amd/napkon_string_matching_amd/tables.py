@@ -182,8 +182,11 @@ class SetTable:
         width = width or pick_width(int(cnt.max()) if n else 1)
         if n and int(cnt.max()) > width:
             raise ValueError(f"row with {int(cnt.max())} ids does not fit width {width}")
-        order = np.argsort(~valid, axis=1, kind="stable")  # valid ids first, input order kept
-        packed = np.take_along_axis(ids, order, axis=1)[:, : min(w_in, width)].astype(np.int32)
+        if w_in < 2 or bool((valid[:, :-1] >= valid[:, 1:]).all()):  # already packed: valid ids first
+            packed = ids[:, : min(w_in, width)].astype(np.int32)
+        else:
+            order = np.argsort(~valid, axis=1, kind="stable")  # valid ids first, input order kept
+            packed = np.take_along_axis(ids, order, axis=1)[:, : min(w_in, width)].astype(np.int32)
         if packed.shape[1] < width:
             packed = np.pad(packed, ((0, 0), (0, width - packed.shape[1])), constant_values=-1)
         if validate and n:
