@@ -22,6 +22,7 @@ The JSON line carries, besides the driver's contract fields:
   roofline      dominant kernel; achieved = algorithmic bytes (128 B per pair) per
                 launch / average kernel duration measured with HIP events on the launch stream
   exhaustive    the same grid with the exact prune disabled (every pair's matrix evaluated)
+  limiter       the pruned kernel against its real bound, the VALU issue rate of the per-row filter
   cpu_baseline  the oracle's restatement of the reference's Python loop, 1 core, bounded sample
 """
 import argparse
@@ -599,6 +600,20 @@ def main():
             "achieved_GBps": roof(k_ms_ex),
             "frac": roof(k_ms_ex) / HBM_PEAK_GBPS,
         },
+    }
+    # The honest limiter of the pruned kernel is the VALU issue rate of its per-row filter, not HBM (DESIGN.md
+    # 4.0/4.1/4.3): filter instructions per (wavefront, left row) x their measured issue cycles
+    # (profiles/r01_valu_issue_rates_gfx950.txt) against the kernel's measured duration.
+    filter_cycles = 8 * 4.3 + 2.3 if work.name == "c3" else 4 * 4.3 + 2.3  # 8 v_sad_u8 + v_or | 2 v_and + 2 v_bcnt + v_and
+    wave_rows = -(-work.m // 64) * work.n
+    ideal_ms = wave_rows * filter_cycles / (256 * 4 * 2.4e9) * 1e3
+    result["limiter"] = {
+        "bound": "valu_issue",
+        "note": "filter cycles per (wavefront, left row) x all wave-rows / (1024 SIMDs x 2.4 GHz); size-class skips "
+                "make the true work smaller, survivors and loop overhead make it larger",
+        "filter_cycles_per_wave_row": filter_cycles,
+        "ideal_kernel_ms": ideal_ms,
+        "frac": ideal_ms / k_ms,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(work, 80_000 if work.name == "c3" else 20_000_000)
