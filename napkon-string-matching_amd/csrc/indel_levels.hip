@@ -301,8 +301,19 @@ __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
 // LCS per pair (all remaining steps compare the same two strings), the remaining weights added step by
 // step in the reference's order.  A row whose park (64 pairs) is full keeps going the wave-wide way.
 // Two barriers per batch; every wave of the block executes the same (category, batch) sequence.
-constexpr int kCoBatch = 8;
-constexpr int kCoSlots = 64;
+// tunables, A/B-measured on C5-shaped cohorts (3 x 100k^2, default 44.3 ms): park 32 / 48 slots per row ->
+// 45.3 / 44.4 ms, chunks of 64 / 256 rows -> 44.3 / 44.5 ms, batches of 16 rows -> 61.4 ms
+#ifndef NSM_CO_BATCH
+#define NSM_CO_BATCH 8
+#endif
+#ifndef NSM_CO_SLOTS
+#define NSM_CO_SLOTS 64
+#endif
+#ifndef NSM_CO_CHUNK
+#define NSM_CO_CHUNK 128
+#endif
+constexpr int kCoBatch = NSM_CO_BATCH;
+constexpr int kCoSlots = NSM_CO_SLOTS;
 
 __global__ __launch_bounds__(kBlock) void indel_levels_coop_kernel(
     const int32_t* __restrict__ lfirst, const int32_t* __restrict__ lnlev, const int32_t* __restrict__ lorig,
@@ -666,6 +677,14 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
                      left_strings->len, right->first, right->nlev, right->orig, right->cat, right->seg,         \
                      right_strings->codes, right_strings->len, hits, hit_count, p)
   if (K == 1 && !std::getenv("NSM_LEVELS_NO_COOP")) {
+    if (left->seg && NSM_CO_CHUNK != 128) {
+      p.rows_per_chunk = NSM_CO_CHUNK;
+      grid.y = (left->n + p.rows_per_chunk - 1) / p.rows_per_chunk;
+      if (grid.y > 65535) {
+        p.rows_per_chunk = (left->n + 65534) / 65535;
+        grid.y = (left->n + p.rows_per_chunk - 1) / p.rows_per_chunk;
+      }
+    }
     // four waves = four right tiles per block, late steps finished together (indel_levels_coop_kernel)
     const size_t co_lds = kWavesPerBlock * (static_cast<size_t>(p.pm_stride) * 8 + kCoBatch * kWave * 8) +
                           kCoBatch * kCoSlots * 20 + 8 + kCoBatch * 4;
