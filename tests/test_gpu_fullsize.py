@@ -171,3 +171,26 @@ def test_c5_full_size_cohort_pair(dev):
         a = synthetic.c5_level_token_lists(hap, slice(i, i + 1))[0]
         b = synthetic.c5_level_token_lists(pop, slice(j, j + 1))[0]
         assert s == ocmp.compare_terms(a, b, osf.intersection_vs_union) and cats_ok(i, j)
+
+
+def test_fuzzy_levels_cooperative_equals_wave_wide(dev, monkeypatch):
+    """The block-cooperative late steps of the one-word fuzzy levels kernel against the wave-wide kernel it
+    replaces (NSM_LEVELS_NO_COOP=1), 25k x 25k C5-shaped items, three thresholds, with and without partition."""
+    from napkon_string_matching_amd import _lib, grid, synthetic, tables
+    from napkon_string_matching_amd.compare import score_functions as sf
+
+    n = 25_000
+    hap = synthetic.c5_cohort(n, 31)
+    pop = synthetic.c5_cohort(n, 32, plant_from=hap)
+    lv = lambda c: [[sf.fuzzy_operand(x) for x in it] for it in synthetic.c5_level_token_lists(c)]
+    la, lb = lv(hap), lv(pop)
+    mode = _lib.CAT_INTERSECT_OR_BOTH_EMPTY
+    for part in (True, False):
+        li, ls, ri, rs = tables.encode_level_strings(la, lb, dev, hap["cat"], pop["cat"], mode, partition=part)
+        for thr in (0.5, 0.7, 0.9):
+            monkeypatch.delenv("NSM_LEVELS_NO_COOP", raising=False)
+            coop = grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode).as_tuples()
+            monkeypatch.setenv("NSM_LEVELS_NO_COOP", "1")
+            plain = grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode).as_tuples()
+            assert coop == plain and len(coop) > 100
+    monkeypatch.delenv("NSM_LEVELS_NO_COOP", raising=False)
