@@ -25,7 +25,20 @@ class Questionnaire(ComparableData):
 
 
 class GeccoDefinition(ComparableData):
-    """GECCO item table; ``Category`` is a single label (a ``str``), which selects the
-    ``x in set(y)`` branch of the category predicate when compared with a questionnaire."""
+    """GECCO item table (gecco_definition.py:34-64); ``Category`` is a single label (a ``str``), which
+    selects the ``x in set(y)`` branch of the category predicate when compared with a questionnaire."""
 
-    __column_mapping__ = {"Id": "Variable"}
+    __column_mapping__ = {}
+
+    def map_for_comparable(self):
+        """gecco_definition.py:41-44 -- the result's Variable column is the item's Identifier."""
+        result = super().map_for_comparable().copy()
+        result["Variable"] = result["Identifier"]
+        return result
+
+    def add_terms(self) -> None:
+        """gecco_definition.py:57-64 -- Term = [category, parameter, choice] without empty parts."""
+        self._data["Term"] = [
+            self.gen_term(category, parameter, choice)
+            for category, parameter, choice in zip(self._data["Category"], self._data["Parameter"], self._data["Choices"])
+        ]

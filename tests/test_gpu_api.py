@@ -183,6 +183,40 @@ def test_matcher_end_to_end(golden):
     assert set(analysis["hap vs Pop"]) == {"matched", "gecco"}
 
 
+def test_matcher_gecco_step(golden):
+    """``match_gecco_with_questionnaires``: GECCO items (scalar category, Variable := Identifier) against every
+    cohort, keys ``gecco vs <name>``; results vs the oracle."""
+    from napkon_string_matching_amd import matching, synthetic
+    from napkon_string_matching_amd.types.questionnaire import GeccoDefinition, Questionnaire
+    from oracle import compare as oc
+
+    frames = {
+        "hap": pd.DataFrame(synthetic.cohort_records("hap", 50, 1, vocab=30, max_entries=4, tokens_per_entry=2)),
+        "pop": pd.DataFrame(synthetic.cohort_records("pop", 45, 2, vocab=30, max_entries=4, tokens_per_entry=2)),
+    }
+    gecco = pd.DataFrame(synthetic.cohort_records("gec", 30, 5, vocab=30, max_entries=4, tokens_per_entry=2))
+    gecco["Category"] = [cats[0] for cats in gecco["Category"]]  # GECCO: one label per item
+    gecco["Parameter"] = [f"p{k}" for k in range(len(gecco))]
+    gecco["Choices"] = [None if k % 3 else "ja nein" for k in range(len(gecco))]
+    gd = GeccoDefinition(gecco.copy())
+    gd.add_terms()
+    assert gd["Term"][0] == [gecco["Category"][0], "p0", "ja nein"] and gd["Term"][1] == [gecco["Category"][1], "p1"]
+    config = {"matching": {"score_threshold": 0.2, "cache_threshold": None, "compare_column": "Tokens",
+                           "score_func": "intersection_vs_union", "filter_categories": True,
+                           "variable_score_threshold": 0.6}, "steps": ["gecco"]}
+    m = matching.match(config, write=False, questionnaires={k: Questionnaire(v) for k, v in frames.items()},
+                       gecco=GeccoDefinition(gecco.copy()))
+    assert sorted(m.results.results) == ["gecco vs hap", "gecco vs pop"]
+    left = gecco.copy()
+    left["Variable"] = left["Identifier"]
+    for name, frame in frames.items():
+        want = oc.compare(left, frame, {}, {}, left_name="gecco", right_name=name, **config["matching"])
+        got = m.results[f"gecco vs {name}"].dataframe()
+        assert list(got.index) == list(want.index) and len(want) > 0
+        assert list(got["MatchScore"]) == list(want["MatchScore"])
+        assert list(got["GeccoVariable"]) == list(want["GeccoVariable"]) == list(got["GeccoIdentifier"])
+
+
 def test_mesh_get_matches_and_add_tokens(golden):
     """Row f1: MeshProvider.get_matches / MatchPreparator.add_tokens through the RAW fuzzy grid."""
     import random
