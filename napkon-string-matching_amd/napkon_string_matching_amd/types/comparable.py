@@ -75,8 +75,28 @@ class Comparable:
     def __repr__(self) -> str:
         return repr(self.data)
 
+    def __str__(self) -> str:
+        return str(self.data)
+
     def dataframe(self) -> pd.DataFrame:
         return self.data
+
+    # -- frame conveniences that keep the cohort names (comparable.py:119-145)
+    def dropna(self, *args, **kwargs) -> "Comparable":
+        return Comparable(self.data.dropna(*args, **kwargs), self.left_name, self.right_name)
+
+    def drop(self, *args, **kwargs) -> "Comparable":
+        return Comparable(self.data.drop(*args, **kwargs), self.left_name, self.right_name)
+
+    def merge(self, *args, **kwargs) -> "Comparable":
+        return Comparable(self.data.merge(*args, **kwargs), self.left_name, self.right_name)
+
+    def drop_superfluous_columns(self, columns=None) -> None:
+        """Keep only ``columns`` (default: the result columns of both sides + MatchScore), in place."""
+        if columns is None:
+            columns = [p + c for p in (self.left_name, self.right_name) for c in COLUMN_NAMES] + [MATCH_SCORE]
+        extra = [c for c in self.data.columns if c not in set(columns)]
+        self.__dict__["data"] = self.data.drop(columns=extra)
 
     def sort_by_score(self) -> None:
         """comparable.py:69-70, made deterministic: score descending, ties by pair label."""

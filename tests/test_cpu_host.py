@@ -279,3 +279,18 @@ def test_signature_word_layout():
     # an id beyond cnt is ignored
     row = np.array([[int(on5[0]), int(on9[0])] + [-1] * 14], dtype=np.int32)
     assert int(tables.signatures(row, np.array([1], np.int32))[0]) == 1 << 5
+
+
+def test_comparable_frame_conveniences():
+    from napkon_string_matching_amd.types.comparable import Comparable
+
+    frame = pd.DataFrame({"HapIdentifier": ["h0", "h1"], "PopIdentifier": ["p0", None], "HapVariable": ["a", "b"],
+                          "PopVariable": ["x", "y"], "Extra": [1, 2], "MatchScore": [0.9, 0.4]})
+    comp = Comparable(frame, "Hap", "Pop")
+    assert str(comp) == str(frame) and len(comp.dropna()) == 1 and comp.dropna().left_name == "Hap"
+    assert list(comp.drop(columns=["Extra"]).dataframe().columns) == [c for c in frame.columns if c != "Extra"]
+    merged = comp.merge(pd.DataFrame({"HapIdentifier": ["h0"], "Note": ["n"]}), on="HapIdentifier")
+    assert isinstance(merged, Comparable) and list(merged["Note"]) == ["n"] and merged.right_name == "Pop"
+    comp.drop_superfluous_columns()
+    assert "Extra" not in comp.dataframe().columns and "MatchScore" in comp.dataframe().columns
+    assert list(comp.match_variable) == ["a", "b"] and list(comp.variable) == ["x", "y"]  # match_<col> is the LEFT side
