@@ -46,7 +46,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=("c2", "c3", "c4", "c5"), default="c2")
+    ap.add_argument("--workload", choices=("c2", "c3", "c4", "c5", "term"), default="c2")
     ap.add_argument("--rows", type=int, default=0, help="override rows per side per GPU (debug)")
     ap.add_argument("--right-rows", type=int, default=0, help="override the right side's rows (debug)")
     ap.add_argument("--threshold", type=float, default=None, help="override the workload's threshold (debug)")
@@ -103,6 +103,32 @@ class Workload:
             self.dtype = "int32"
             self.label = (f"{name.upper()}: {n}x{m} token-id sets/GPU (Poisson(8) ids, W=16), intersection_vs_union RAW, "
                           f"threshold {self.threshold}")
+        elif name == "term":
+            # the reference's DEFAULT configuration (config.yml:11-14,22): compare_column Term, score_func
+            # fuzzy_match, gen_comparable at cache_threshold 0.5, no category filter -> levels mode over joined
+            # level strings of 60..240 code units (multi-word LCS).  The right cohort is the same on every rank.
+            from napkon_string_matching_amd.compare import score_functions as sf
+
+            n = rows or 20_000
+            m = right_rows or rows or 20_000
+            self.threshold = 0.5 if threshold is None else threshold
+            left_items = synthetic.term_cohort(n, 1234 + 1000 * rank)
+            right_items = synthetic.term_cohort(m, 5678, plant_from=synthetic.term_cohort(n, 1234))
+            self.left_np = [[sf.fuzzy_operand(lv) for lv in it] for it in synthetic.term_levels(left_items)]
+            self.right_np = [[sf.fuzzy_operand(lv) for lv in it] for it in synthetic.term_levels(right_items)]
+            t_enc = time.perf_counter()
+            self.term_tables = tables.encode_level_strings(self.left_np, self.right_np, device, left_offset=rank * n)
+            torch.cuda.synchronize(device)
+            self.encode_h2d_seconds = time.perf_counter() - t_enc
+            li, ls, ri, rs = self.term_tables
+            self.left, self.right = ls, rs
+            self.term_structs = (li.struct(), ls.struct(), ri.struct(), rs.struct())
+            self.kernel = f"indel_levels_kernel<{ls.stride // 64}>"
+            self.dtype = "u64"
+            lens = [len(s) for it in self.left_np for s in it[1:]]
+            self.label = (f"TERM: {n}x{m} Term-shaped items/GPU (3-5 entries -> 3-5 suffix-nested levels, joined level strings "
+                          f"mean {sum(lens) / max(1, len(lens)):.0f} / max {max(lens)} code units, stride {ls.stride}), "
+                          f"compare_terms x fuzzy_match, no categories, threshold {self.threshold}")
         else:
             n = rows or 200_000
             m = right_rows or rows or 200_000
@@ -130,6 +156,10 @@ class Workload:
             self.label = f"C3: {n}x{m} strings/GPU (len U[16,64], 37 symbols), fuzzy_match RAW, threshold {self.threshold}"
         self.n, self.m = n, m
         self.ls, self.rs = self.left.struct(), self.right.struct()
+        self.bytes_per_pair = BYTES_PER_PAIR
+        if name == "term":  # both items' level strings (mean levels x row stride)
+            li, ls, ri, rs = self.term_tables
+            self.bytes_per_pair = int(round((ls.n / max(1, li.n) + rs.n / max(1, ri.n)) * ls.stride))
 
     @staticmethod
     def _share_right(planted, like, device, world):
@@ -150,6 +180,15 @@ class Workload:
         from napkon_string_matching_amd import _lib
 
         flags = self.flag_prune if prune else 0
+        if self.name == "term":  # prune off = every step scored wave-wide (no parking, no histogram bound)
+            st = self.term_structs
+            flags = self.flag_prune if prune else _lib.FLAG_WAVE_WIDE
+            _lib.check(
+                self.lib.nsm_indel_levels_grid(st[0], st[1], st[2], st[3], float(self.threshold), _lib.CAT_NONE, flags,
+                                               buf.records.data_ptr(), buf.capacity, buf.count.data_ptr(), stream),
+                self.kernel,
+            )
+            return
         _lib.check(
             self.launch_fn(self.ls, self.rs, float(self.threshold), flags, buf.records.data_ptr(), buf.capacity,
                            buf.count.data_ptr(), stream),
@@ -187,6 +226,17 @@ def cpu_baseline(work, budget_pairs):
         hits = oc.raw_grid_hits(left, right, "intersection_vs_union", work.threshold)
         dt = time.perf_counter() - t0
         sample = f"{side}x{side} sub-grid of the same corpus, set-based intersection_vs_union per pair (Python)"
+    elif work.name == "term":
+        from oracle import native
+
+        side = int(budget_pairs ** 0.5)
+        cps = lambda items: [[[ord(c) for c in s] for s in it] for it in items]
+        left, right = cps(work.left_np[:side]), cps(work.right_np[:side])
+        t0 = time.perf_counter()
+        hits = native.levels(True, left, right, work.threshold, None, None, 0, cap=side * side)
+        dt = time.perf_counter() - t0
+        sample = (f"{side}x{side} sub-grid, compare_terms x Indel ratio per pair by the C oracle (O(nm) LCS DP per level "
+                  "pair, scalar C, NOT rapidfuzz, NOT the reference's Python loop)")
     else:
         side = int(budget_pairs ** 0.5)
         left = synthetic.decode_strings(work.left_np[0][:side], work.left_np[1][:side])
@@ -437,6 +487,8 @@ def main():
 
     if args.workload == "c4" and args.capacity == 1 << 13:
         args.capacity = 1 << 16  # ~12k hits at 1M x 1M
+    if args.workload == "term" and args.capacity == 1 << 13:
+        args.capacity = 1 << 24  # ~2.3 % of the pairs reach the cache threshold 0.5
     if args.workload == "c5":
         run_c5(args, rank, world, device, dist)
         if world > 1:
@@ -543,7 +595,7 @@ def main():
     k_ms_ex = kernel_ms(False, ex_steps)
 
     def roof(ms):
-        achieved = work.n * work.m * BYTES_PER_PAIR / (ms * 1e-3) / 1e9
+        achieved = work.n * work.m * work.bytes_per_pair / (ms * 1e-3) / 1e9
         return achieved
 
     traffic = None
@@ -569,8 +621,8 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": work.label,
-            "score_func": "fuzzy_match" if work.name == "c3" else "intersection_vs_union",
-            "mode": "RAW",
+            "score_func": "fuzzy_match" if work.name in ("c3", "term") else "intersection_vs_union",
+            "mode": "MATCHER" if work.name == "term" else "RAW",
             "threshold": work.threshold,
             "pairs_per_step": pairs_per_step,
             "hits_per_rank": n_hits,
@@ -589,7 +641,7 @@ def main():
             "traffic": traffic,
             "hbm_measured_GBps": None if traffic is None else traffic / (k_ms * 1e-3) / 1e9,
             "kernel_ms": k_ms,
-            "algorithmic_bytes_per_launch": work.n * work.m * BYTES_PER_PAIR,
+            "algorithmic_bytes_per_launch": work.n * work.m * work.bytes_per_pair,
             "compulsory_hbm_bytes_per_launch": work.left.nbytes() + work.right.nbytes() + n_hits * 16,
         },
         "exhaustive": {
@@ -616,7 +668,7 @@ def main():
         "frac": ideal_ms / k_ms,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(work, 80_000 if work.name == "c3" else 20_000_000)
+        result["cpu_baseline"] = cpu_baseline(work, {"c3": 80_000, "term": 360_000}.get(work.name, 20_000_000))
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -145,6 +145,8 @@ typedef struct nsm_level_items {
 #define NSM_CAT_INTERSECT_OR_BOTH_EMPTY 2 /* list x list */
 
 #define NSM_FLAG_PRUNE 1u /* exact signature / length bound before the full comparison */
+#define NSM_FLAG_WAVE_WIDE 2u /* nsm_indel_levels_grid: score every step wave-wide (no block-cooperative
+                                 parking of the surviving pairs); same hits, kept for A/B runs and tests */
 
 int nsm_abi_version(void);
 const char* nsm_last_error(void);

@@ -11,8 +11,6 @@
 // its own right level row (64 B, re-loaded only when its level index changes) and runs the
 // bit-parallel LCS; the double ratio and the power-of-two weighted sum follow the reference's
 // operation order.
-#include <cstdlib>
-
 #include "indel_wide.hpp"
 
 namespace nsm {
@@ -338,6 +336,7 @@ __global__ __launch_bounds__(kBlock) void indel_levels_coop_kernel(
   int32_t* park_meta = park_jorig + kCoBatch * kCoSlots;
   unsigned long long& s_cats = *reinterpret_cast<unsigned long long*>(park_meta + kCoBatch * kCoSlots);
   int* s_park_cnt = reinterpret_cast<int*>(&s_cats + 1);
+  int* s_park_valid = s_park_cnt + kCoBatch;  // slots [0, valid) of a row are written (see the reservation)
   const uint32_t pm_base = static_cast<uint32_t>(wave * wave_bytes);  // s_pm starts at LDS offset 0
 
   const int tile = blockIdx.x * kWavesPerBlock + wave;
@@ -351,7 +350,10 @@ __global__ __launch_bounds__(kBlock) void indel_levels_coop_kernel(
 
   // the categories of the block's four tiles
   if (threadIdx.x == 0) s_cats = 0ull;
-  if (threadIdx.x < kCoBatch) s_park_cnt[threadIdx.x] = 0;
+  if (threadIdx.x < kCoBatch) {
+    s_park_cnt[threadIdx.x] = 0;
+    s_park_valid[threadIdx.x] = kCoSlots;
+  }
   __syncthreads();
   if (partitioned) {
     const unsigned long long mine = wave_or_u64(valid ? (1ull << myseg) : 0ull);
@@ -420,8 +422,11 @@ __global__ __launch_bounds__(kBlock) void indel_levels_coop_kernel(
           int have = 0;
           if (lane == 0) have = atomicAdd(&s_park_cnt[r], n);
           have = __builtin_amdgcn_readfirstlane(have);
-          if (have + n > kCoSlots) {  // park full: give the slots back, this row goes on the wave-wide way
-            if (lane == 0) atomicSub(&s_park_cnt[r], n);
+          if (have + n > kCoSlots) {
+            // park full: this row goes on the wave-wide way.  The counter is NOT rolled back (a rollback
+            // races with the other waves' reservations); it stays inflated, so every later reservation
+            // fails too, and the written slots are exactly [0, first failing offset).
+            if (lane == 0) atomicMin(&s_park_valid[r], have);
             continue;
           }
           if (alive) {
@@ -521,7 +526,7 @@ __global__ __launch_bounds__(kBlock) void indel_levels_coop_kernel(
 
   // ---- the parked pairs of batch row r, lanes = the pairs (from all four tiles)
   auto finish_row = [&](int ib, int r) __attribute__((always_inline)) {
-    const int n = min(s_park_cnt[r], kCoSlots);
+    const int n = min(s_park_cnt[r], s_park_valid[r]);  // valid <= kCoSlots
     if (n <= 0) return;
     const int i = ib + r;
     const int ll = lnlev[i];
@@ -593,7 +598,10 @@ __global__ __launch_bounds__(kBlock) void indel_levels_coop_kernel(
       __syncthreads();  // every tile's survivors of this batch are parked
       for (int r = wave; r < nrows; r += kWavesPerBlock) {
         finish_row(ib, r);
-        if (lane == 0) s_park_cnt[r] = 0;  // after this wave's own reads of it
+        if (lane == 0) {  // after this wave's own reads of them
+          s_park_cnt[r] = 0;
+          s_park_valid[r] = kCoSlots;
+        }
       }
       __syncthreads();  // the park has been read and emptied
     }
@@ -607,7 +615,6 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
                                      double threshold, int32_t category_mode, uint32_t flags, nsm_hit* hits,
                                      uint64_t capacity, unsigned long long* hit_count, void* stream) {
   using namespace nsm;
-  (void)flags;
   if (!left || !right || !left_strings || !right_strings || !hit_count || (!hits && capacity)) {
     set_error("nsm_indel_levels_grid: null argument");
     return NSM_E_BADARG;
@@ -676,7 +683,7 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
                      left->first, left->nlev, left->orig, left->cat, left->seg_start, left_strings->codes,     \
                      left_strings->len, right->first, right->nlev, right->orig, right->cat, right->seg,         \
                      right_strings->codes, right_strings->len, hits, hit_count, p)
-  if (K == 1 && !std::getenv("NSM_LEVELS_NO_COOP")) {
+  if (K == 1 && !(flags & NSM_FLAG_WAVE_WIDE)) {
     if (left->seg && NSM_CO_CHUNK != 128) {
       p.rows_per_chunk = NSM_CO_CHUNK;
       grid.y = (left->n + p.rows_per_chunk - 1) / p.rows_per_chunk;
@@ -687,7 +694,7 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
     }
     // four waves = four right tiles per block, late steps finished together (indel_levels_coop_kernel)
     const size_t co_lds = kWavesPerBlock * (static_cast<size_t>(p.pm_stride) * 8 + kCoBatch * kWave * 8) +
-                          kCoBatch * kCoSlots * 20 + 8 + kCoBatch * 4;
+                          kCoBatch * kCoSlots * 20 + 8 + kCoBatch * 8;
     hipLaunchKernelGGL(indel_levels_coop_kernel, grid, dim3(kBlock), co_lds, static_cast<hipStream_t>(stream),
                        left->first, left->nlev, left->orig, left->cat, left->seg_start, left_strings->codes,
                        left_strings->len, right->first, right->nlev, right->orig, right->cat, right->seg,

@@ -8,6 +8,7 @@ LIB_PATH = Path(os.environ.get("NSM_HIP_LIBRARY", _HERE.parent / "csrc" / "libns
 
 ABI_VERSION = 1
 FLAG_PRUNE = 1
+FLAG_WAVE_WIDE = 2  # nsm_indel_levels_grid without the block-cooperative parking (A/B runs, tests)
 CAT_NONE, CAT_INTERSECT, CAT_INTERSECT_OR_BOTH_EMPTY = 0, 1, 2
 
 c_i32p = ctypes.c_void_p  # device pointers travel as integers

@@ -203,3 +203,61 @@ def c5_level_token_lists(cohort: dict, rows: slice = slice(None)) -> List[List[L
 
 def c5_category_lists(cohort: dict, rows: slice = slice(None)) -> List[List[str]]:
     return [[f"cat{b}" for b in range(64) if (int(m) >> b) & 1] for m in cohort["cat"][rows]]
+
+
+# ------------------------------------------------------------------ "term": the reference's default configuration
+_TERM_LETTERS = "enisratdhulcgmobwfkzvpjyxq"
+
+
+def term_vocabulary(vocab: int = 5000, seed: int = 99) -> List[str]:
+    """German-looking words: letters drawn with a skewed distribution, 3..12 letters."""
+    rng = np.random.default_rng(seed)
+    letters = np.array(list(_TERM_LETTERS))
+    weight = 1.0 / np.arange(1, len(letters) + 1) ** 0.7
+    weight /= weight.sum()
+    return ["".join(rng.choice(letters, size=int(rng.integers(3, 13)), p=weight)) for _ in range(vocab)]
+
+
+def term_cohort(n: int, seed: int, vocab: int = 5000, entries=(3, 5), words=(2, 5), plant_from: list = None,
+                plant_fraction: float = 0.01) -> List[List[List[str]]]:
+    """Items shaped like the reference's ``Term`` column (config.yml:13 ``compare_column: Term``): a list of
+    3..5 entries (sheet header, sub-headers, question, options -- types/questionnaire.py:59-68), each a few
+    Zipf-distributed words.  Returns per item its entries as word lists; ``term_levels`` turns them into what
+    ``gen_comp_value`` yields.  ``plant_from``: ``plant_fraction`` of the items are copies of random items of
+    that cohort with one word replaced (near-duplicates, so that above-threshold pairs exist)."""
+    rng = np.random.default_rng(seed)
+    lex = term_vocabulary(vocab)
+    zipf = 1.0 / np.arange(1, vocab + 1)
+    zipf /= zipf.sum()
+    n_entries = rng.integers(entries[0], entries[1] + 1, size=n)
+    n_words = rng.integers(words[0], words[1] + 1, size=int(n_entries.sum()))
+    picks = rng.choice(vocab, size=int(n_words.sum()), p=zipf)
+    items, e_at, w_at = [], 0, 0
+    for k in range(n):
+        item = []
+        for _ in range(int(n_entries[k])):
+            c = int(n_words[e_at])
+            item.append([lex[v] for v in picks[w_at: w_at + c]])
+            e_at += 1
+            w_at += c
+        items.append(item)
+    if plant_from is not None:
+        for t in rng.choice(n, size=max(1, int(round(plant_fraction * n))), replace=False):
+            src = [list(e) for e in plant_from[int(rng.integers(0, len(plant_from)))]]
+            e = int(rng.integers(0, len(src)))
+            src[e][int(rng.integers(0, len(src[e])))] = lex[int(rng.integers(0, vocab))]
+            items[int(t)] = src
+    return items
+
+
+def term_levels(items: List[List[List[str]]]) -> List[List[List[str]]]:
+    """``gen_comp_value`` of every item (types/comparable_data.py:283-285 with a whitespace tokenizer):
+    level l = the sorted distinct words of the last l + 1 entries."""
+    out = []
+    for item in items:
+        levels = []
+        for lv in range(1, len(item) + 1):
+            words = {w for entry in item[-lv:] for w in entry}
+            levels.append(sorted(words, key=str.casefold))
+        out.append(levels)
+    return out

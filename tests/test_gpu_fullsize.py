@@ -173,9 +173,9 @@ def test_c5_full_size_cohort_pair(dev):
         assert s == ocmp.compare_terms(a, b, osf.intersection_vs_union) and cats_ok(i, j)
 
 
-def test_fuzzy_levels_cooperative_equals_wave_wide(dev, monkeypatch):
+def test_fuzzy_levels_cooperative_equals_wave_wide(dev):
     """The block-cooperative late steps of the one-word fuzzy levels kernel against the wave-wide kernel it
-    replaces (NSM_LEVELS_NO_COOP=1), 25k x 25k C5-shaped items, three thresholds, with and without partition."""
+    replaces (NSM_FLAG_WAVE_WIDE), 25k x 25k C5-shaped items, three thresholds, with and without partition."""
     from napkon_string_matching_amd import _lib, grid, synthetic, tables
     from napkon_string_matching_amd.compare import score_functions as sf
 
@@ -188,9 +188,6 @@ def test_fuzzy_levels_cooperative_equals_wave_wide(dev, monkeypatch):
     for part in (True, False):
         li, ls, ri, rs = tables.encode_level_strings(la, lb, dev, hap["cat"], pop["cat"], mode, partition=part)
         for thr in (0.5, 0.7, 0.9):
-            monkeypatch.delenv("NSM_LEVELS_NO_COOP", raising=False)
             coop = grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode).as_tuples()
-            monkeypatch.setenv("NSM_LEVELS_NO_COOP", "1")
-            plain = grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode).as_tuples()
+            plain = grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, wave_wide=True).as_tuples()
             assert coop == plain and len(coop) > 100
-    monkeypatch.delenv("NSM_LEVELS_NO_COOP", raising=False)

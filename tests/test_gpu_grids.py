@@ -334,6 +334,39 @@ def test_indel_levels_random(dev, max_levels):
             _same_hits(got, want)
 
 
+@pytest.mark.parametrize("thr", [0.0, 0.05, 0.1, 0.3])
+def test_indel_levels_park_overflow(dev, thr):
+    """Low thresholds keep nearly every pair alive, so the block-shared park of the one-word kernel
+    overflows with uneven per-wave counts (partial last tile, category predicate): the cooperative kernel,
+    the wave-wide kernel (NSM_FLAG_WAVE_WIDE) and the oracle must agree (round-1 ADVICE: the rolled-back
+    reservation raced)."""
+    from napkon_string_matching_amd import _lib, grid, tables
+    from oracle import native
+
+    rng = random.Random(4242)
+    words = ["".join(rng.choice("abcdefgh") for _ in range(rng.randint(2, 5))) for _ in range(40)]
+
+    def item():
+        n = rng.randint(3, 6)
+        toks = [rng.choice(words) for _ in range(n + 1)]
+        return [" ".join(sorted(set(toks[: k + 2]))) for k in range(n)]  # suffix-nested, <= 64 code units
+
+    left, right = [item() for _ in range(83)], [item() for _ in range(64 * 4 * 2 + 37)]
+    assert max(len(s) for it in left + right for s in it) <= 64
+    lcat = np.array([rng.choice([1, 2, 3, 4, 6]) for _ in left], dtype=np.uint64)
+    rcat = np.array([rng.choice([1, 2, 3, 5]) for _ in right], dtype=np.uint64)
+    cps = lambda items: [[[ord(c) for c in s] for s in it] for it in items]
+    for mode, partition in ((_lib.CAT_INTERSECT, True), (_lib.CAT_INTERSECT, False), (_lib.CAT_NONE, False)):
+        li, ls, ri, rs = tables.encode_level_strings(left, right, dev, lcat, rcat, mode, partition=partition)
+        assert ls.stride == 64
+        want = native.levels(True, cps(left), cps(right), thr, lcat, rcat, mode, cap=1 << 17)
+        coop = grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, capacity=1 << 16)
+        plain = grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, capacity=1 << 16, wave_wide=True)
+        assert coop.as_tuples() == plain.as_tuples()
+        _same_hits(coop, want)
+        assert len(want) > 5000
+
+
 @pytest.mark.parametrize("hi", [90, 230, 480])
 def test_indel_levels_long_strings(dev, hi):
     from napkon_string_matching_amd import _lib, grid, tables
