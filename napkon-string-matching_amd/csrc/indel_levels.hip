@@ -285,330 +285,9 @@ __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
 }
 
 
-// ---------------------------------------------------------------------------------------------------
-// One-word strings: the four waves of a block (= four right tiles) finish the late steps TOGETHER.
-//
-// Measured on C5-shaped cohorts: after step 2 only 6.4 % of the (left row, right item) pairs can still
-// reach 0.7, yet one such lane among 64 keeps a whole wave scanning step 3 -- a third of the kernel at
-// 6 % lane utilisation.  Here every wave still scans ITS tile step-major against the batch of 8 left
-// rows, but as soon as every remaining step of the batch compares the LAST level of both items (both
-// level indices clamped, at the earliest before step 3) the pairs that can still reach the threshold
-// are PARKED in block-shared LDS -- per left row: last right level row, caller's right id, partial
-// score, next step -- and after a barrier each wave finishes two of the eight rows with its lanes =
-// that row's parked pairs from all four tiles (right strings gathered from L2): one mask table, one
-// LCS per pair (all remaining steps compare the same two strings), the remaining weights added step by
-// step in the reference's order.  A row whose park (64 pairs) is full keeps going the wave-wide way.
-// Two barriers per batch; every wave of the block executes the same (category, batch) sequence.
-// tunables, A/B-measured on C5-shaped cohorts (3 x 100k^2, default 44.3 ms): park 32 / 48 slots per row ->
-// 45.3 / 44.4 ms, chunks of 64 / 256 rows -> 44.3 / 44.5 ms, batches of 16 rows -> 61.4 ms
-#ifndef NSM_CO_BATCH
-#define NSM_CO_BATCH 8
-#endif
-#ifndef NSM_CO_SLOTS
-#define NSM_CO_SLOTS 64
-#endif
-#ifndef NSM_CO_CHUNK
-#define NSM_CO_CHUNK 128
-#endif
-constexpr int kCoBatch = NSM_CO_BATCH;
-constexpr int kCoSlots = NSM_CO_SLOTS;
-
-__global__ __launch_bounds__(kBlock) void indel_levels_coop_kernel(
-    const int32_t* __restrict__ lfirst, const int32_t* __restrict__ lnlev, const int32_t* __restrict__ lorig,
-    const uint64_t* __restrict__ lcat, const int32_t* __restrict__ lsegstart, const uint8_t* __restrict__ lcodes,
-    const int32_t* __restrict__ llen, const int32_t* __restrict__ rfirst, const int32_t* __restrict__ rnlev,
-    const int32_t* __restrict__ rorig, const uint64_t* __restrict__ rcat, const int32_t* __restrict__ rseg,
-    const uint8_t* __restrict__ rcodes, const int32_t* __restrict__ rlen, nsm_hit* __restrict__ hits,
-    unsigned long long* __restrict__ count, const IndelLevParams p) {
-  // LDS: per wave [pm_stride] masks + [8][64] running scores; per block the park: [8][64] score (f64),
-  // last right level row, caller's right id, lb | next step << 8 | right depth << 16 (i32 each), [8] counters
-  // (everything lives in the dynamic region: the text images hold raw LDS addresses relative to offset 0)
-  extern __shared__ __attribute__((aligned(16))) unsigned long long s_pm[];
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wave = threadIdx.x >> 6;
-  const size_t wave_bytes = static_cast<size_t>(p.pm_stride) * 8 + kCoBatch * kWave * 8;
-  unsigned char* wbase = reinterpret_cast<unsigned char*>(s_pm) + wave * wave_bytes;
-  unsigned long long* pm = reinterpret_cast<unsigned long long*>(wbase);
-  double* sc = reinterpret_cast<double*>(wbase + static_cast<size_t>(p.pm_stride) * 8);
-  double* park_score = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(s_pm) + kWavesPerBlock * wave_bytes);
-  int32_t* park_rrow = reinterpret_cast<int32_t*>(park_score + kCoBatch * kCoSlots);
-  int32_t* park_jorig = park_rrow + kCoBatch * kCoSlots;
-  int32_t* park_meta = park_jorig + kCoBatch * kCoSlots;
-  unsigned long long& s_cats = *reinterpret_cast<unsigned long long*>(park_meta + kCoBatch * kCoSlots);
-  int* s_park_cnt = reinterpret_cast<int*>(&s_cats + 1);
-  int* s_park_valid = s_park_cnt + kCoBatch;  // slots [0, valid) of a row are written (see the reservation)
-  const uint32_t pm_base = static_cast<uint32_t>(wave * wave_bytes);  // s_pm starts at LDS offset 0
-
-  const int tile = blockIdx.x * kWavesPerBlock + wave;
-  const int j = tile * kWave + lane;
-  const bool valid = j < p.n_right;  // a whole wave may be beyond the table: it still takes part in the block's work
-  const int jc = valid ? j : p.n_right - 1;
-  const bool partitioned = rseg != nullptr;
-  const int myseg = partitioned ? rseg[jc] : 0;
-  const int i0 = blockIdx.y * p.rows_per_chunk;
-  const int i1 = min(p.n_left, i0 + p.rows_per_chunk);
-
-  // the categories of the block's four tiles
-  if (threadIdx.x == 0) s_cats = 0ull;
-  if (threadIdx.x < kCoBatch) {
-    s_park_cnt[threadIdx.x] = 0;
-    s_park_valid[threadIdx.x] = kCoSlots;
-  }
-  __syncthreads();
-  if (partitioned) {
-    const unsigned long long mine = wave_or_u64(valid ? (1ull << myseg) : 0ull);
-    if (lane == 0 && mine) atomicOr(&s_cats, mine);
-  } else if (threadIdx.x == 0) {
-    s_cats = 1ull;
-  }
-  __syncthreads();
-  const unsigned long long cats_block = s_cats;  // block-uniform from here on
-  if (partitioned) {  // most (tiles, chunk) combinations hold no row of the tiles' categories: leave early
-    bool work = false;
-    for (unsigned long long cats = cats_block; cats;) {
-      const int c = __builtin_ctzll(cats);
-      cats &= cats - 1;
-      work = work || (max(i0, lsegstart[c]) < min(i1, lsegstart[c + 1]));
-    }
-    if (!work) return;  // the whole block
-  }
-
-  const int lr = rnlev[jc];
-  const int rrow0 = rfirst[jc];
-  const int jorig = rorig[jc];
-  const uint64_t catr = (p.cat_mode != NSM_CAT_NONE) ? rcat[jc] : 0ull;
-  const int lr_max = wave_max_i32(valid ? lr : 0);
-  const int rrow_last = rrow0 + max(0, lr - 1);
-  const int lb_last = rlen[rrow_last];
-
-  uint32_t lowmask = 0xffffu, sh16 = 16u;  // kept in VGPRs: e32 ops with VGPR operands issue at full rate
-
-  auto ratio_of = [](int la_, int lb_, int lcs_) -> double {
-    return (la_ == 0 || lb_ == 0) ? 0.0 : g_ratio64.v[(la_ + lb_) * 65 + lcs_];
-  };
-
-  // ---- this wave's tile against the batch rows [ib, ib + nrows): the step-major scan of
-  // indel_levels_kernel, plus parking
-  auto scan_batch = [&](int ib, int nrows, uint32_t okbits, uint32_t live) __attribute__((always_inline)) {
-    // the text image does not outlive the batch (step 1 of the next batch needs another level anyway), so
-    // its 32 registers are free during the dense pass
-    uint32_t taddr[32];
-    int text_row = -1;
-    int lb = 0;
-    for (int r = 0; r < nrows; ++r) sc[r * kWave + lane] = 0.0;
-    int ll_max = 0;
-    for (uint32_t rows = live; rows;) {
-      const int r = __builtin_ctz(rows);
-      rows &= rows - 1;
-      ll_max = max(ll_max, lnlev[ib + r]);
-    }
-    const int steps_max = max(ll_max, lr_max);
-    const int clamped_from = max(3, steps_max - 1);  // from this step on both level indices are clamped
-    double factor = 1.0;
-    for (int s = 1; s <= steps_max && live; ++s) {
-      if (s >= clamped_from) {
-        // park the pairs that can still reach the threshold; `factor` is the weight of step s - 1
-        for (uint32_t rows = live; rows;) {
-          const int r = __builtin_ctz(rows);
-          rows &= rows - 1;
-          const double score = sc[r * kWave + lane];
-          const bool alive = ((okbits >> r) & 1u) && s <= max(lnlev[ib + r], lr) && (score + factor + 1e-9 >= p.threshold);
-          const unsigned long long who = __ballot(alive);
-          if (who == 0ull) {  // nothing left of this row in this tile
-            live &= ~(1u << r);
-            continue;
-          }
-          const int n = __popcll(who);
-          int have = 0;
-          if (lane == 0) have = atomicAdd(&s_park_cnt[r], n);
-          have = __builtin_amdgcn_readfirstlane(have);
-          if (have + n > kCoSlots) {
-            // park full: this row goes on the wave-wide way.  The counter is NOT rolled back (a rollback
-            // races with the other waves' reservations); it stays inflated, so every later reservation
-            // fails too, and the written slots are exactly [0, first failing offset).
-            if (lane == 0) atomicMin(&s_park_valid[r], have);
-            continue;
-          }
-          if (alive) {
-            const int slot = r * kCoSlots + have + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(who >> 32),
-                                                       __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(who), 0u));
-            park_score[slot] = score;
-            park_rrow[slot] = rrow_last;
-            park_jorig[slot] = jorig;
-            park_meta[slot] = lb_last | (s << 8) | (lr << 16);
-            sc[r * kWave + lane] = __builtin_nan("");  // never a hit from this side
-          }
-          live &= ~(1u << r);
-        }
-        if (!live) break;
-      }
-      factor *= 0.5;
-      // right level of this step (per lane): rebuild the address image only when the row changes
-      const int rrow = rrow0 + max(0, min(s, lr - 1));
-      if (rrow != text_row) {
-        text_row = rrow;
-        const uint4* tp = reinterpret_cast<const uint4*>(rcodes + static_cast<size_t>(rrow) * 64);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const uint4 v = tp[q];
-          const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const uint32_t c0 = w[e] & 0xffu, c1 = (w[e] >> 8) & 0xffu, c2 = (w[e] >> 16) & 0xffu, c3 = w[e] >> 24;
-            taddr[8 * q + 2 * e + 0] = (pm_base + 8 * c0) | ((pm_base + 8 * c1) << 16);
-            taddr[8 * q + 2 * e + 1] = (pm_base + 8 * c2) | ((pm_base + 8 * c3) << 16);
-          }
-        }
-        lb = rlen[rrow];
-      }
-      const int nchars = wave_max_i32(okbits ? lb : 0);
-      for (uint32_t rows = live; rows;) {
-        const int r = __builtin_ctz(rows);
-        rows &= rows - 1;
-        const int i = ib + r;
-        const int ll = lnlev[i];
-        if (s > max(ll, lr_max)) {  // every lane has seen all its steps of this row
-          live &= ~(1u << r);
-          continue;
-        }
-        const bool active = ((okbits >> r) & 1u) && s <= max(ll, lr);
-        const int lrow = lfirst[i] + max(0, min(s, ll - 1));
-        const int la = llen[lrow];
-        wide_build_pm<1>(pm, p.pm_stride, lcodes + static_cast<size_t>(lrow) * 64, la, lane);
-        int lcs;
-        const int npairs = (nchars + 1) >> 1;
-        asm volatile("" : "+v"(lowmask), "+v"(sh16));  // see indel_levels_kernel
-        if (la <= 32) {
-          uint32_t v = ~0u;
-#pragma unroll
-          for (int w = 0; w < 32; ++w) {
-            if (w < npairs) {
-              const uint32_t m0 = lev_lds_load<uint32_t>(taddr[w] & lowmask);
-              const uint32_t u0 = v & m0;
-              v = (v + u0) | (v ^ u0);
-              const uint32_t m1 = lev_lds_load<uint32_t>(taddr[w] >> sh16);
-              const uint32_t u1 = v & m1;
-              v = (v + u1) | (v ^ u1);
-            }
-          }
-          lcs = 32 - __popc(v);
-        } else {
-          unsigned long long v = ~0ull;
-#pragma unroll
-          for (int w = 0; w < 32; ++w) {
-            if (w < npairs) {
-              const unsigned long long m0 = lev_lds_load<unsigned long long>(taddr[w] & lowmask);
-              const unsigned long long u0 = v & m0;
-              v = lev_add64(v, u0) | (v ^ u0);
-              const unsigned long long m1 = lev_lds_load<unsigned long long>(taddr[w] >> sh16);
-              const unsigned long long u1 = v & m1;
-              v = lev_add64(v, u1) | (v ^ u1);
-            }
-          }
-          lcs = 64 - __popcll(v);
-        }
-        double score = sc[r * kWave + lane];
-        if (active) {
-          score += ratio_of(la, lb, lcs) * factor;
-          sc[r * kWave + lane] = score;
-        }
-        if (!__any(active && (score + factor + 1e-9 >= p.threshold))) live &= ~(1u << r);
-      }
-    }
-    for (int r = 0; r < nrows; ++r) {
-      const double score = sc[r * kWave + lane];
-      const bool hit = ((okbits >> r) & 1u) && score >= p.threshold;  // false for the parked (NaN) pairs
-      if (__any(hit)) {
-        if (hit) emit_hit(hits, p.cap, count, score, lorig[ib + r], jorig);
-      }
-    }
-  };
-
-  // ---- the parked pairs of batch row r, lanes = the pairs (from all four tiles)
-  auto finish_row = [&](int ib, int r) __attribute__((always_inline)) {
-    const int n = min(s_park_cnt[r], s_park_valid[r]);  // valid <= kCoSlots
-    if (n <= 0) return;
-    const int i = ib + r;
-    const int ll = lnlev[i];
-    const int lrow = lfirst[i] + ll - 1;  // the left item's last level
-    const int la = llen[lrow];
-    const bool active = lane < n;
-    const int slot = r * kCoSlots + (active ? lane : 0);
-    const int rrow = park_rrow[slot];  // the right item's last level
-    const int meta = park_meta[slot];
-    const int lbj = meta & 0xff, s0 = (meta >> 8) & 0xff, lrj = meta >> 16;
-    // the lane's text is requested first: its latency overlaps the mask build
-    uint32_t text[16];
-    const uint4* tp = reinterpret_cast<const uint4*>(rcodes + static_cast<size_t>(rrow) * 64);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const uint4 v = tp[q];
-      text[4 * q + 0] = v.x;
-      text[4 * q + 1] = v.y;
-      text[4 * q + 2] = v.z;
-      text[4 * q + 3] = v.w;
-    }
-    wide_build_pm<1>(pm, p.pm_stride, lcodes + static_cast<size_t>(lrow) * 64, la, lane);
-    const int nwords = (wave_max_i32(active ? lbj : 0) + 3) >> 2;
-    unsigned long long v = ~0ull;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) {
-      if (w < nwords) {
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const unsigned c = (text[w] >> (8 * b)) & 0xffu;
-          const unsigned long long m = pm[c];
-          const unsigned long long u = v & m;
-          v = lev_add64(v, u) | (v ^ u);
-        }
-      }
-    }
-    const int lcs = 64 - __popcll(v);
-    if (active) {
-      const double ratio = ratio_of(la, lbj, lcs);
-      double score = park_score[slot];
-      double factor = __builtin_ldexp(1.0, 1 - s0);  // the weight of step s0 - 1
-      const int last = max(ll, lrj);
-      for (int s = s0; s <= last; ++s) {  // the remaining steps all compare these two strings
-        factor *= 0.5;
-        score += ratio * factor;
-      }
-      if (score >= p.threshold) emit_hit(hits, p.cap, count, score, lorig[i], park_jorig[slot]);
-    }
-  };
-
-  for (unsigned long long cats = cats_block; cats;) {  // the same sequence in every wave of the block
-    const int c = __builtin_ctzll(cats);
-    cats &= cats - 1;
-    const int a = partitioned ? max(i0, lsegstart[c]) : i0;
-    const int b = partitioned ? min(i1, lsegstart[c + 1]) : i1;
-    const unsigned long long lower = (1ull << c) - 1ull;
-    for (int ib = a; ib < b; ib += kCoBatch) {
-      const int nrows = min(kCoBatch, b - ib);
-      uint32_t okbits = 0, live = 0;
-      for (int r = 0; r < nrows; ++r) {
-        const uint64_t cl = (p.cat_mode != NSM_CAT_NONE) ? lcat[ib + r] : 0ull;
-        bool ok = valid;
-        if (partitioned) ok = ok && myseg == c && ((cl & catr & lower) == 0ull);
-        else if (p.cat_mode != NSM_CAT_NONE) ok = ok && category_match(cl, catr, p.cat_mode);
-        okbits |= ok ? (1u << r) : 0u;
-        live |= __any(ok) ? (1u << r) : 0u;
-      }
-      if (live) scan_batch(ib, nrows, okbits, live);
-      __syncthreads();  // every tile's survivors of this batch are parked
-      for (int r = wave; r < nrows; r += kWavesPerBlock) {
-        finish_row(ib, r);
-        if (lane == 0) {  // after this wave's own reads of them
-          s_park_cnt[r] = 0;
-          s_park_valid[r] = kCoSlots;
-        }
-      }
-      __syncthreads();  // the park has been read and emptied
-    }
-  }
-}
-
 }  // namespace nsm
+
+#include "indel_levels_park.hpp"
 
 extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_table* left_strings,
                                      const nsm_level_items* right, const nsm_str_table* right_strings,
@@ -683,22 +362,46 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
                      left->first, left->nlev, left->orig, left->cat, left->seg_start, left_strings->codes,     \
                      left_strings->len, right->first, right->nlev, right->orig, right->cat, right->seg,         \
                      right_strings->codes, right_strings->len, hits, hit_count, p)
-  if (K == 1 && !(flags & NSM_FLAG_WAVE_WIDE)) {
-    if (left->seg && NSM_CO_CHUNK != 128) {
-      p.rows_per_chunk = NSM_CO_CHUNK;
-      grid.y = (left->n + p.rows_per_chunk - 1) / p.rows_per_chunk;
-      if (grid.y > 65535) {
-        p.rows_per_chunk = (left->n + 65534) / 65535;
-        grid.y = (left->n + p.rows_per_chunk - 1) / p.rows_per_chunk;
-      }
+  if (!(flags & NSM_FLAG_WAVE_WIDE)) {
+    // scan + park + dense finish (indel_levels_park.hpp)
+    ParkParams q;
+    q.n_left = left->n; q.n_right = right->n; q.cap = capacity;
+    q.cat_mode = category_mode;
+    q.threshold = threshold;
+    q.use_hist = ((flags & NSM_FLAG_PRUNE) && left_strings->hist && right_strings->hist) ? 1 : 0;
+    q.pm_stride = (left_strings->alphabet + 1 + 7) / 8 * 8;
+    const int batch = park_batch(K);
+    q.park_slots = 128;
+    q.park_max = 24;
+    q.rows_per_chunk = p.rows_per_chunk;
+    const size_t tbl_bytes = static_cast<size_t>(q.pm_stride) * K * 8;
+    const size_t fixed_wave = (K > 1 ? 16 * K * kWave * 4 : 0) + batch * kWave * 2 +
+                              batch * 3 * kHeadDwords * 4 + batch * kWave * K;
+    const size_t park_bytes = static_cast<size_t>(q.park_slots) * kSub * 16 + 66 * 16 + 8 + 4 * kSub * 4;
+    // one-word text images hold 16-bit LDS addresses: the block stays under 64 KiB (and so do the others)
+    const size_t budget = 60 * 1024;
+    int pw = 4;  // waves (= right tiles) per block: as many as fit with one mask table each ...
+    while (pw > 1 && pw * (tbl_bytes + fixed_wave) + park_bytes > budget) pw >>= 1;
+    q.fin_rows = batch;  // ... then as many tables for the dense pass as fit
+    while (q.fin_rows > 1 && pw * (q.fin_rows * tbl_bytes + fixed_wave) + park_bytes > budget) --q.fin_rows;
+    const size_t park_lds = pw * (q.fin_rows * tbl_bytes + fixed_wave) + park_bytes;
+    if (park_lds > 64 * 1024) {
+      set_error("nsm_indel_levels_grid: alphabet %d at stride %d needs %zu bytes of LDS", left_strings->alphabet,
+                stride, park_lds);
+      return NSM_E_UNSUPPORTED;
     }
-    // four waves = four right tiles per block, late steps finished together (indel_levels_coop_kernel)
-    const size_t co_lds = kWavesPerBlock * (static_cast<size_t>(p.pm_stride) * 8 + kCoBatch * kWave * 8) +
-                          kCoBatch * kCoSlots * 20 + 8 + kCoBatch * 8;
-    hipLaunchKernelGGL(indel_levels_coop_kernel, grid, dim3(kBlock), co_lds, static_cast<hipStream_t>(stream),
-                       left->first, left->nlev, left->orig, left->cat, left->seg_start, left_strings->codes,
-                       left_strings->len, right->first, right->nlev, right->orig, right->cat, right->seg,
-                       right_strings->codes, right_strings->len, hits, hit_count, p);
+    dim3 pgrid((n_tiles + pw - 1) / pw, grid.y);
+#define NSM_LAUNCH_PARK(KK)                                                                                       \
+  hipLaunchKernelGGL((indel_levels_park_kernel<KK>), pgrid, dim3(pw * kWave), park_lds,                          \
+                     static_cast<hipStream_t>(stream), left->first, left->nlev, left->orig, left->cat,           \
+                     left->seg_start, left_strings->codes, left_strings->len, left_strings->hist, right->first,  \
+                     right->nlev, right->orig, right->cat, right->seg, right_strings->codes, right_strings->len, \
+                     right_strings->hist, hits, hit_count, q)
+    if (K == 1) NSM_LAUNCH_PARK(1);
+    else if (K == 2) NSM_LAUNCH_PARK(2);
+    else if (K == 4) NSM_LAUNCH_PARK(4);
+    else NSM_LAUNCH_PARK(8);
+#undef NSM_LAUNCH_PARK
   } else if (K == 1) NSM_LAUNCH_LEVELS(1);
   else if (K == 2) NSM_LAUNCH_LEVELS(2);
   else if (K == 4) NSM_LAUNCH_LEVELS(4);

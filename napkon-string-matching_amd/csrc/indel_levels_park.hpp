@@ -11,18 +11,20 @@
 // (configs[4], threshold 0.7: 49 % of the pairs survive step 1 on weights alone, 0.9 % with the bound).
 // A wavefront that keeps scanning for those few lanes wastes the other ~63, so:
 //
-//   H     per (left row of the batch, lane = right item): R = upper bound of the steps >= 2 from the
-//         histograms of their level strings -> the smallest step-1 LCS that keeps the pair alive, an
-//         integer `need` (0xffff = the pair cannot hit or fails the category predicate); rows without a
-//         live lane are never scored;
+//   stage per batch of left rows the wave copies what it needs of them into its LDS once: per row and step
+//         1..3 the level string's length, row and histogram ("head"), and the step's level strings
+//         themselves -- two memory latencies per batch instead of a dependent chain per row;
+//   H     per (left row, lane = right item): R = upper bound of the steps >= 2 from the histograms ->
+//         the smallest step-1 LCS that keeps the pair alive, an integer `need` (0xffff = the pair cannot
+//         hit or fails the category predicate); rows without a live lane are never scored;
 //   scan  step 1 wave-wide (lane = right item, left level wave-uniform, bit-parallel LCS); lanes with
 //         lcs >= need survive.  Few survivors (<= park_max lanes): they are PARKED in block-shared LDS
 //         as (score so far, right item row, batch row, next step).  Many survivors: the row goes on
 //         wave-wide, step by step, with the same test (and the chance to park) after every step;
-//   dense after a barrier the block's waves share the parked pairs of the batch, 64 per pass, lane =
-//         one pair: match-mask tables of the batch's left rows side by side in the wave's LDS, the
-//         lane's right level string gathered from L2, remaining steps in the reference's order with the
-//         histogram bound after each; hits are emitted from here.
+//   dense every kSub batches the block meets at a barrier; each wave takes the parked pairs of one
+//         batch, 64 per pass, lane = one pair: match-mask tables of that batch's left rows side by side
+//         in the wave's LDS, the lane's right level string gathered from L2, remaining steps in the
+//         reference's order with the histogram bound after each; hits are emitted from here.
 //
 // Every test that drops a pair is an upper bound (exact: hits are identical to the wave-wide kernel's).
 #pragma once
@@ -37,22 +39,24 @@ struct ParkParams {
   int32_t cat_mode;
   int32_t use_hist;    // both string tables carry histograms and NSM_FLAG_PRUNE is set
   int32_t fin_rows;    // mask tables per wave in the dense pass (1 .. batch)
-  int32_t park_slots;  // capacity of the block's park
+  int32_t park_slots;  // capacity of ONE park region (there are kSub)
   int32_t park_max;    // park a row's survivors when at most this many of the 64 lanes are alive
   double threshold;
   unsigned long long cap;
 };
 
 constexpr int park_batch(int K) { return K >= 4 ? 4 : 8; }
+constexpr int kSub = 4;  // scan batches (= park regions) between two barriers
 constexpr uint16_t kDeadNeed = 0xffff;
-
-// LCS <= (la + lb - L1) / 2 with L1 the distance of the bucketed symbol histograms, so
-// ratio = 2 LCS / (la + lb) <= 1 - L1 / (la + lb); 0 when either string is empty (QRatio).  float with a
-// relative error of ~1e-7: every user adds a margin.
-__device__ __forceinline__ float hist_ratio_ub(uint32_t l1, int la, int lb) {
-  const float n = static_cast<float>(la + lb);
-  return (la == 0 || lb == 0) ? 0.0f : 1.0f - static_cast<float>(l1) * __builtin_amdgcn_rcpf(n);
-}
+#ifndef NSM_X_GROUPS
+#define NSM_X_GROUPS 8
+#endif
+// 4 waves per SIMD (128 VGPRs): left alone hipcc settles at 169 VGPRs = 2 waves, and the kernel's latency-bound
+// phases then run 1.4x slower (3 x 100k^2 levels bench: 38.4 vs 26.7 ms); the spills this forces sit in the dense pass
+#ifndef NSM_PARK_OCC
+#define NSM_PARK_OCC __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
+constexpr int kHeadDwords = 12;  // histogram (4 folded / 8 dwords) | la | row | levels | first row
 
 template <int NB>
 __device__ __forceinline__ uint32_t hist_l1(const uint32_t (&a)[NB], const uint32_t (&b)[NB]) {
@@ -76,6 +80,14 @@ __device__ __forceinline__ void load_hist(const uint8_t* __restrict__ hist, int 
   }
 }
 
+// LCS <= (la + lb - L1) / 2 with L1 the distance of the bucketed symbol histograms, so
+// ratio = 2 LCS / (la + lb) <= 1 - L1 / (la + lb).  float with a relative error of ~1e-7: every user adds a
+// margin.  (Both strings empty: the bound says 1 where the ratio is 0 -- weaker, still a bound.)
+__device__ __forceinline__ float hist_ratio_ub(uint32_t l1, int la, int lb) {
+  const float n = static_cast<float>(max(la + lb, 1));
+  return 1.0f - static_cast<float>(l1) * __builtin_amdgcn_rcpf(n);
+}
+
 // Upper bound of sum_{t > s} 2^-t * ratio_t for a pair with S steps, from the histogram bound `ub` of step
 // s + 1: the steps after s + 1 repeat that level pair when both level indices are clamped (s + 1 >= S - 1),
 // otherwise they are bounded by 1.
@@ -86,8 +98,35 @@ __device__ __forceinline__ float rest_bound(int s, int S, float ub) {
   return wt * ub + tail * ((s + 1 >= S - 1) ? ub : 1.0f);
 }
 
+
+// One code unit of Hyyro's LCS recurrence, V' = (V + (V & M)) | (V ^ (V & M)), spelled as e32 instructions:
+// left to itself hipcc fuses the expression into three v_bitop3_b32 and an add per code unit, and VOP3 ops
+// issue at half the rate of e32 ops with VGPR operands (profiles/r01_valu_issue_rates_gfx950.txt).
+__device__ __forceinline__ uint32_t lcs_step32(uint32_t v, uint32_t m) {
+  uint32_t u, t, x, r;
+  asm("v_and_b32 %0, %1, %2" : "=v"(u) : "v"(v), "v"(m));
+  asm("v_add_u32 %0, %1, %2" : "=v"(t) : "v"(v), "v"(u));
+  asm("v_xor_b32 %0, %1, %2" : "=v"(x) : "v"(v), "v"(u));
+  asm("v_or_b32 %0, %1, %2" : "=v"(r) : "v"(t), "v"(x));
+  return r;
+}
+
+__device__ __forceinline__ unsigned long long lcs_step64(unsigned long long v, unsigned long long m) {
+  const uint32_t vl = static_cast<uint32_t>(v), vh = static_cast<uint32_t>(v >> 32);
+  const uint32_t ml = static_cast<uint32_t>(m), mh = static_cast<uint32_t>(m >> 32);
+  uint32_t ul, uh, xl, xh, rl, rh;
+  asm("v_and_b32 %0, %1, %2" : "=v"(ul) : "v"(vl), "v"(ml));
+  asm("v_and_b32 %0, %1, %2" : "=v"(uh) : "v"(vh), "v"(mh));
+  const unsigned long long t = lev_add64(v, (static_cast<unsigned long long>(uh) << 32) | ul);
+  asm("v_xor_b32 %0, %1, %2" : "=v"(xl) : "v"(vl), "v"(ul));
+  asm("v_xor_b32 %0, %1, %2" : "=v"(xh) : "v"(vh), "v"(uh));
+  asm("v_or_b32 %0, %1, %2" : "=v"(rl) : "v"(static_cast<uint32_t>(t)), "v"(xl));
+  asm("v_or_b32 %0, %1, %2" : "=v"(rh) : "v"(static_cast<uint32_t>(t >> 32)), "v"(xh));
+  return (static_cast<unsigned long long>(rh) << 32) | rl;
+}
+
 template <int K>
-__global__ __launch_bounds__(kBlock) void indel_levels_park_kernel(
+__global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
     const int32_t* __restrict__ lfirst, const int32_t* __restrict__ lnlev, const int32_t* __restrict__ lorig,
     const uint64_t* __restrict__ lcat, const int32_t* __restrict__ lsegstart, const uint8_t* __restrict__ lcodes,
     const int32_t* __restrict__ llen, const uint8_t* __restrict__ lhist, const int32_t* __restrict__ rfirst,
@@ -97,9 +136,10 @@ __global__ __launch_bounds__(kBlock) void indel_levels_park_kernel(
     const ParkParams p) {
   // LDS (dynamic, starts at offset 0 -- the one-word text images hold raw LDS addresses):
   //   per wave: [fin_rows][pm_stride * K] u64 mask tables (the scan uses table 0)
-  //             (K > 1) [16 K][64] u32 text image | [batch][64] f64 running scores | [batch][64] u16 need
-  //   per block: park score f64[P] | right item row i32[P] | batch row | next step << 8 i32[P] |
-  //              cats u64 | count[2] valid[2] i32
+  //             (K > 1) [16 K][64] u32 text image | [batch][64] u16 need (then the step-1 LCS)
+  //             | [batch][3][12] u32 heads | [batch][64 K] u8 the step's left level strings
+  //   per block: kSub park regions of park_slots: score f64 | right item row i32 | batch row + next step << 8 i32
+  //              | [66] float4 step weights by S | cats u64 | count[2][kSub] valid[2][kSub] i32
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_mem[];
   constexpr int kRow = kWave * K;      // code units per string row
   constexpr int kBatch = park_batch(K);
@@ -110,19 +150,22 @@ __global__ __launch_bounds__(kBlock) void indel_levels_park_kernel(
 
   const int tbl_entries = p.pm_stride * K;
   const size_t wave_bytes = static_cast<size_t>(p.fin_rows) * tbl_entries * 8 + (K > 1 ? 16 * K * kWave * 4 : 0) +
-                            kBatch * kWave * 8 + kBatch * kWave * 2;
+                            kBatch * kWave * 2 + kBatch * 3 * kHeadDwords * 4 + kBatch * kRow;
   unsigned char* wbase = reinterpret_cast<unsigned char*>(s_mem) + wave * wave_bytes;
   unsigned long long* pm = reinterpret_cast<unsigned long long*>(wbase);
   uint32_t* wtext = reinterpret_cast<uint32_t*>(pm + static_cast<size_t>(p.fin_rows) * tbl_entries);
-  double* sc = reinterpret_cast<double*>(wtext + (K > 1 ? 16 * K * kWave : 0));
-  uint16_t* need = reinterpret_cast<uint16_t*>(sc + kBatch * kWave);
+  uint16_t* need = reinterpret_cast<uint16_t*>(wtext + (K > 1 ? 16 * K * kWave : 0));
+  uint32_t* head = reinterpret_cast<uint32_t*>(need + kBatch * kWave);
+  uint8_t* lstr = reinterpret_cast<uint8_t*>(head + kBatch * 3 * kHeadDwords);
   unsigned char* bbase = reinterpret_cast<unsigned char*>(s_mem) + waves * wave_bytes;
+  const int park_total = p.park_slots * kSub;
   double* park_score = reinterpret_cast<double*>(bbase);
-  int32_t* park_j = reinterpret_cast<int32_t*>(park_score + p.park_slots);
-  int32_t* park_meta = park_j + p.park_slots;
-  unsigned long long& s_cats = *reinterpret_cast<unsigned long long*>(park_meta + p.park_slots);
-  int* s_cnt = reinterpret_cast<int*>(&s_cats + 1);  // [2], by batch parity
-  int* s_valid = s_cnt + 2;                           // [2]: slots [0, valid) are written
+  int32_t* park_j = reinterpret_cast<int32_t*>(park_score + park_total);
+  int32_t* park_meta = park_j + park_total;
+  float4* wtab = reinterpret_cast<float4*>(park_meta + park_total);
+  unsigned long long& s_cats = *reinterpret_cast<unsigned long long*>(wtab + 66);
+  int* s_cnt = reinterpret_cast<int*>(&s_cats + 1);  // [2][kSub], by super-batch parity
+  int* s_valid = s_cnt + 2 * kSub;                    // [2][kSub]: slots [0, valid) are written
   const uint32_t pm_base = static_cast<uint32_t>(wave * wave_bytes);
 
   const int tile = blockIdx.x * waves + wave;
@@ -134,12 +177,20 @@ __global__ __launch_bounds__(kBlock) void indel_levels_park_kernel(
   const int i0 = blockIdx.y * p.rows_per_chunk;
   const int i1 = min(p.n_left, i0 + p.rows_per_chunk);
   const bool use_hist = p.use_hist != 0;
-  const float thr_f = static_cast<float>(p.threshold);
 
   if (threadIdx.x == 0) s_cats = 0ull;
-  if (threadIdx.x < 2) {
+  if (threadIdx.x < 2 * kSub) {
     s_cnt[threadIdx.x] = 0;
     s_valid[threadIdx.x] = p.park_slots;
+  }
+  // step weights of a pair with S steps: R = w2 * ub2 + w3 * ub3 + c bounds the steps >= 2 (rest_bound with
+  // both histogram levels), stored as {w2, w3, threshold - (w2 + w3 + c)}
+  for (int S = threadIdx.x; S < 66; S += blockDim.x) {
+    const double pS = __builtin_ldexp(1.0, -S);
+    const double w2 = S >= 2 ? 0.25 : 0.0;
+    const double w3 = S >= 3 ? 0.125 + (S <= 4 ? 0.125 - pS : 0.0) : 0.0;
+    const double c = S > 4 ? 0.125 - pS : 0.0;
+    wtab[S] = make_float4(static_cast<float>(w2), static_cast<float>(w3), static_cast<float>(p.threshold - (w2 + w3 + c)), 0.0f);
   }
   __syncthreads();
   if (partitioned) {
@@ -180,273 +231,105 @@ __global__ __launch_bounds__(kBlock) void indel_levels_park_kernel(
   }
 
   uint32_t lowmask = 0xffffu, sh16 = 16u;  // kept in VGPRs: e32 ops with VGPR operands issue at full rate
+  // the lane's text of the current step; step 1 always reads the same level, so the image survives from
+  // batch to batch unless a row went on wave-wide
+  uint32_t taddr[K == 1 ? 32 : 1];
+  int text_row = -1;
+  int lb = 0;
 
   auto ratio_of = [](int la_, int lb_, int lcs_) -> double {
-    if constexpr (K == 1) return (la_ == 0 || lb_ == 0) ? 0.0 : g_ratio64.v[(la_ + lb_) * 65 + lcs_];
+    // (the index is clamped: an idle lane's operands must never turn into a wild read)
+    if constexpr (K == 1) return (la_ == 0 || lb_ == 0) ? 0.0 : g_ratio64.v[min((la_ + lb_) * 65 + lcs_, 129 * 65 - 1)];
     else return indel_score_dev(la_, lb_, lcs_);
   };
 
   // per-lane histogram bound of one step's level pair, both rows gathered (continuation and dense pass)
   auto step_ub = [&](int lrow, int rrow, int la_, int lb_) -> float {
-    if (!use_hist) return (la_ == 0 || lb_ == 0) ? 0.0f : 1.0f;
+    if (!use_hist) return 1.0f;
     uint32_t a[8], b[8];
     load_hist<8>(lhist, lrow, a);
     load_hist<8>(rhist, rrow, b);
     return hist_ratio_ub(hist_l1<8>(a, b), la_, lb_);
   };
 
-  // reserve n park slots of parity pb for this wave; -1 when the park is full.  The counter is never rolled
-  // back (a rollback races with the other waves' reservations): it stays inflated, every later reservation
-  // fails too, and the written slots are exactly [0, first failing offset).
-  auto reserve = [&](int pb, int n) -> int {
+  // reserve n slots of park region `reg` for this wave; -1 when the region is full.  The counter is never
+  // rolled back (a rollback races with the other waves' reservations): it stays inflated, every later
+  // reservation fails too, and the written slots are exactly [0, first failing offset).
+  auto reserve = [&](int reg, int n) -> int {
     int have = 0;
-    if (lane == 0) have = atomicAdd(&s_cnt[pb], n);
+    if (lane == 0) have = atomicAdd(&s_cnt[reg], n);
     have = __builtin_amdgcn_readfirstlane(have);
     if (have + n > p.park_slots) {
-      if (lane == 0) atomicMin(&s_valid[pb], have);
+      if (lane == 0) atomicMin(&s_valid[reg], have);
       return -1;
     }
     return have;
   };
 
-  // ---- this wave's tile against the batch rows [ib, ib + nrows); okbits bit r = the lane passes the
-  // category predicate for row ib + r
-  auto scan_batch = [&](int ib, int nrows, uint32_t okbits, uint32_t rows_ok, int pb) __attribute__((always_inline)) {
-    // ---- H: need[r][lane]
-    uint32_t live = 0;
-    for (uint32_t rows = rows_ok; rows;) {
-      const int r = __builtin_ctz(rows);
-      rows &= rows - 1;
-      const int i = ib + r;
-      const int ll = lnlev[i];
-      const int lf = lfirst[i];
-      const int S = max(ll, lr);
-      float ub[3];
-      int la1 = 0, m1 = 0;
+  // copy the level strings of step s of the rows in `rows` into the wave's LDS (lane = one dword of one row)
+  auto stage_strings = [&](int ib, uint32_t rows, int s) __attribute__((always_inline)) {
+    constexpr int kDw = 16 * K;              // dwords per string row
+    constexpr int kPer = kWave / kDw > 0 ? kWave / kDw : 1;  // rows per pass (K = 1: 4, K = 2: 2, K >= 4: 1)
+    constexpr int kPass = kDw > kWave ? kDw / kWave : 1;     // passes per row (K = 8: 2)
+    for (int r0 = 0; r0 < kBatch; r0 += kPer) {
+      const int r = r0 + (kPer > 1 ? lane / kDw : 0);
+      const bool on = r < kBatch && ((rows >> r) & 1u);
+      if (!__any(on)) continue;
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        const int lrow = lf + max(0, min(t + 1, ll - 1));
-        const int la = llen[lrow];
-        uint32_t l1 = 0;
-        if (use_hist) {
-          uint32_t hl[NB];
-          load_hist<NB>(lhist, lrow, hl);  // wave-uniform row: scalar loads
-          l1 = hist_l1<NB>(hl, hb[t]);
-          ub[t] = hist_ratio_ub(l1, la, lb_t[t]);
-        } else {
-          ub[t] = (la == 0 || lb_t[t] == 0) ? 0.0f : 1.0f;
-          l1 = static_cast<uint32_t>(abs(la - lb_t[t]));
-        }
-        if (t == 0) {
-          la1 = la;
-          m1 = (la + lb_t[0] - static_cast<int>(l1)) >> 1;  // LCS of step 1 <= m1 (<= min(la, lb))
-        }
-      }
-      const float R = (S >= 2 ? 0.25f * ub[1] : 0.0f) + rest_bound(2, S, ub[2]);
-      const int n1 = la1 + lb_t[0];
-      // alive after step 1  <=>  lcs / n1 + R >= thr; 2e-3 of an LCS unit covers the float rounding
-      const float needf = (thr_f - R) * static_cast<float>(n1) - 2e-3f;
-      const int nd = max(0, static_cast<int>(__builtin_ceilf(needf)));
-      const bool ok = (okbits >> r) & 1u;
-      const bool can = ok && nd <= m1;
-      need[r * kWave + lane] = can ? static_cast<uint16_t>(nd) : kDeadNeed;
-      live |= __any(can) ? (1u << r) : 0u;
-    }
-    if (!live) return;
-
-    uint32_t taddr[K == 1 ? 32 : 1];
-    int text_row = -1;
-    int lb = 0;
-    uint32_t cont = 0;  // rows that go on wave-wide after step 1 (running scores in sc, NaN = dropped)
-    int ll_max = 0;
-    for (uint32_t rows = live; rows;) {
-      const int r = __builtin_ctz(rows);
-      rows &= rows - 1;
-      ll_max = max(ll_max, lnlev[ib + r]);
-    }
-    const int steps_max = max(ll_max, lr_max);
-    double factor = 1.0;
-    uint32_t todo = live;
-    for (int s = 1; s <= steps_max && todo; ++s) {
-      factor *= 0.5;
-      // right level of this step (per lane): rebuild the text image only when the row changes
-      const int rrow = rrow0 + max(0, min(s, lr - 1));
-      if constexpr (K == 1) {
-        if (rrow != text_row) {
-          text_row = rrow;
-          const uint4* tp = reinterpret_cast<const uint4*>(rcodes + static_cast<size_t>(rrow) * 64);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const uint4 v = tp[q];
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const uint32_t c0 = w[e] & 0xffu, c1 = (w[e] >> 8) & 0xffu, c2 = (w[e] >> 16) & 0xffu, c3 = w[e] >> 24;
-              taddr[8 * q + 2 * e + 0] = (pm_base + 8 * c0) | ((pm_base + 8 * c1) << 16);
-              taddr[8 * q + 2 * e + 1] = (pm_base + 8 * c2) | ((pm_base + 8 * c3) << 16);
-            }
+      for (int q = 0; q < kPass; ++q) {
+        const int dw = (kPer > 1 ? lane % kDw : lane) + q * kWave;
+        if (on) {
+          int lrow;
+          if (s <= 3) lrow = static_cast<int>(head[(r * 3 + (s - 1)) * kHeadDwords + NB + 1]);
+          else {
+            const int i = ib + r;
+            lrow = lfirst[i] + max(0, min(s, lnlev[i] - 1));
           }
-          lb = rlen[rrow];
-        }
-      } else {
-        if (__any(rrow != text_row)) {  // the LDS image is rewritten by the whole wave
-          text_row = rrow;
-          wide_store_text<K>(wtext, rcodes + static_cast<size_t>(rrow) * kRow, lane);
-          lb = rlen[rrow];
-        }
-      }
-      const int nchars = wave_max_i32(valid ? lb : 0);
-      for (uint32_t rows = todo; rows;) {
-        const int r = __builtin_ctz(rows);
-        rows &= rows - 1;
-        const int i = ib + r;
-        const int ll = lnlev[i];
-        const int S = max(ll, lr);
-        // lanes still in play for this row
-        double score = 0.0;
-        bool run;
-        int nd = 0;
-        if (s == 1) {
-          nd = need[r * kWave + lane];
-          run = nd != kDeadNeed;
-        } else {
-          score = sc[r * kWave + lane];
-          run = (score == score) && s <= S;  // NaN = dropped
-        }
-        if (!__any(run)) {  // (s > 1) nothing left to score: finished lanes keep their scores in sc
-          todo &= ~(1u << r);
-          continue;
-        }
-        const int lrow = lfirst[i] + max(0, min(s, ll - 1));
-        const int la = llen[lrow];
-        wide_build_pm<K>(pm, p.pm_stride, lcodes + static_cast<size_t>(lrow) * kRow, la, lane);
-        int lcs;
-        if constexpr (K == 1) {
-          const int npairs = (nchars + 1) >> 1;
-          // opaque per row: otherwise the 64 unpacked addresses are hoisted out of the row loop into 64
-          // more VGPRs
-          asm volatile("" : "+v"(lowmask), "+v"(sh16));
-          if (la <= 32) {  // wave-uniform: 32-bit words, and / add / xor / or all issue at full rate
-            uint32_t v = ~0u;
-#pragma unroll
-            for (int w = 0; w < 32; ++w) {
-              if (w < npairs) {
-                const uint32_t m0 = lev_lds_load<uint32_t>(taddr[w] & lowmask);
-                const uint32_t u0 = v & m0;
-                v = (v + u0) | (v ^ u0);
-                const uint32_t m1 = lev_lds_load<uint32_t>(taddr[w] >> sh16);
-                const uint32_t u1 = v & m1;
-                v = (v + u1) | (v ^ u1);
-              }
-            }
-            lcs = 32 - __popc(v);
-          } else {
-            unsigned long long v = ~0ull;
-#pragma unroll
-            for (int w = 0; w < 32; ++w) {
-              if (w < npairs) {
-                const unsigned long long m0 = lev_lds_load<unsigned long long>(taddr[w] & lowmask);
-                const unsigned long long u0 = v & m0;
-                v = lev_add64(v, u0) | (v ^ u0);
-                const unsigned long long m1 = lev_lds_load<unsigned long long>(taddr[w] >> sh16);
-                const unsigned long long u1 = v & m1;
-                v = lev_add64(v, u1) | (v ^ u1);
-              }
-            }
-            lcs = 64 - __popcll(v);
-          }
-        } else {
-          lcs = wide_lcs<K>(pm, wtext, nchars, lane, la);
-        }
-        bool alive;  // can still reach the threshold
-        if (s == 1) {
-          alive = run && lcs >= nd;
-          if (!__any(alive)) {
-            todo &= ~(1u << r);
-            continue;
-          }
-          score = ratio_of(la, lb, lcs) * factor;
-        } else {
-          if (run) score += ratio_of(la, lb, lcs) * factor;
-          // steps still to come: histogram bound of the next level pair (exact upper bound; 1e-6 covers
-          // the float arithmetic of the bound and the rounding of the double sum)
-          float rest = 0.0f;
-          if (s < S) {
-            const int t = s + 1;
-            const int lrow_n = lfirst[i] + max(0, min(t, ll - 1));
-            const int rrow_n = rrow0 + max(0, min(t, lr - 1));
-            rest = rest_bound(s, S, step_ub(lrow_n, rrow_n, llen[lrow_n], rlen[rrow_n]));
-          }
-          alive = run && (score + static_cast<double>(rest) + 1e-6 >= p.threshold);
-          if (run && !alive) score = __builtin_nan("");
-        }
-        // pairs that have seen their last step are final
-        const bool more = alive && s < S;
-        if (s == 1) {
-          const bool hit = alive && !more && score >= p.threshold;
-          if (__any(hit)) {
-            if (hit) emit_hit(hits, p.cap, count, score, lorig[i], jorig);
-          }
-        }
-        const unsigned long long who = __ballot(more);
-        if (who == 0ull) {
-          if (s > 1) sc[r * kWave + lane] = score;  // finished or dropped; hits of this row are emitted below
-          todo &= ~(1u << r);
-          continue;
-        }
-        const int n = __popcll(who);
-        int have = -1;
-        if (n <= p.park_max) have = reserve(pb, n);
-        if (have >= 0) {
-          if (more) {
-            const int slot = have + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(who >> 32),
-                                                              __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(who), 0u));
-            park_score[slot] = score;
-            park_j[slot] = jc;
-            park_meta[slot] = r | ((s + 1) << 8);
-            score = __builtin_nan("");  // the dense pass owns the pair now
-          }
-          if (s > 1) sc[r * kWave + lane] = score;
-          todo &= ~(1u << r);
-          continue;
-        }
-        // dense enough (or the park is full): the row goes on wave-wide
-        if (s == 1) {
-          sc[r * kWave + lane] = more ? score : __builtin_nan("");
-          cont |= 1u << r;
-        } else {
-          sc[r * kWave + lane] = score;
+          const uint32_t v = reinterpret_cast<const uint32_t*>(lcodes + static_cast<size_t>(lrow) * kRow)[dw];
+          reinterpret_cast<uint32_t*>(lstr + r * kRow)[dw] = v;
         }
       }
     }
-    for (uint32_t rows = cont; rows;) {
-      const int r = __builtin_ctz(rows);
-      rows &= rows - 1;
-      const double score = sc[r * kWave + lane];
-      const bool hit = score >= p.threshold;  // false for NaN (dropped or parked)
-      if (__any(hit)) {
-        if (hit) emit_hit(hits, p.cap, count, score, lorig[ib + r], jorig);
-      }
-    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   };
 
-  // ---- dense pass: parked pairs [base, base + 64) of the batch, lane = one pair
-  auto finish_pass = [&](int ib, int nrows, int base, int n_p) __attribute__((always_inline)) {
-    const bool active = base + lane < n_p;
-    const int slot = active ? base + lane : base;
-    const int meta = park_meta[slot];
-    const int r = meta & 0xff, s0 = meta >> 8;
-    const int jr = park_j[slot];
-    double score = park_score[slot];
+  // match masks of the staged string of row r (la code units) into table 0
+  auto build_pm_staged = [&](int r, int la) __attribute__((always_inline)) {
+    for (int c = lane; c < tbl_entries; c += kWave) pm[c] = 0ull;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int pos = lane + kWave * k;
+      if (pos < la) {
+        const unsigned c = lstr[r * kRow + pos];
+        atomicOr(&pm[c * K + k], 1ull << lane);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  // ---- remaining steps of up to 64 pairs, lane = one pair (left row ib + r of the batch, right item row jr,
+  // next step s0, score so far -- or, `packed`, the step-1 LCS in the score's bits).  Used for the parked
+  // pairs (reg < 0) and for a row whose step-1 survivors were too many to park (reg >= 0: the lanes are the
+  // wave's own tile; leftovers may still be parked once they are few).
+  auto dense_steps = [&](int ib, int nrows, bool active, int r, int jr, int s0, double score, bool packed,
+                         int reg) __attribute__((always_inline)) {
     const int i = ib + r;
     const int ll = lnlev[i], lf = lfirst[i];
     const int lrj = rnlev[jr], rr0 = rfirst[jr];
+    if (packed && active) {  // the score of step 1 is 2^-1 * ratio (idle lanes carry no LCS: never index the table with one)
+      const int lcs1 = static_cast<int>(__double_as_longlong(score));
+      score = ratio_of(llen[lf + max(0, min(1, ll - 1))], rlen[rr0 + max(0, min(1, lrj - 1))], lcs1) * 0.5;
+    }
     const int S = max(ll, lrj);
-    const int s_lo = -wave_max_i32(active ? 64 - s0 : 0) + 64;  // smallest next step (steps <= 64)
+    const int s_lo = 64 - wave_max_i32(active ? 64 - s0 : 0);  // smallest next step (steps <= 64)
     const int s_hi = wave_max_i32(active ? S : 0);
     int prev_a = -1, prev_b = -1;
     double ratio = 0.0;
-    bool alive = active;
+    bool alive = active;  // still a candidate: running, or finished with its final score
     double factor = __builtin_ldexp(1.0, 1 - s_lo);  // the weight of step s_lo - 1
     for (int s = s_lo; s <= s_hi; ++s) {
       factor *= 0.5;
@@ -460,19 +343,30 @@ __global__ __launch_bounds__(kBlock) void indel_levels_park_kernel(
         int lcs = 0;
         for (int g0 = 0; g0 < nrows; g0 += p.fin_rows) {
           const bool mine = fresh && r >= g0 && r < g0 + p.fin_rows;
-          uint32_t rows_here = wave_reduce_u32(mine ? (1u << r) : 0u, [](uint32_t x, uint32_t y) { return x | y; });
+          const uint32_t rows_here = wave_reduce_u32(mine ? (1u << r) : 0u, [](uint32_t x, uint32_t y) { return x | y; });
           if (!rows_here) continue;
+          // the group's mask tables, one per left row present: request every row's code units first, then
+          // zero, then set the bits (one memory latency for the group instead of one per row)
           int la_max = 0;
-          for (uint32_t rows = rows_here; rows;) {  // the group's mask tables, one per left row present
+          for (int c = lane; c < p.fin_rows * tbl_entries; c += kWave) pm[c] = 0ull;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          for (uint32_t rows = rows_here; rows;) {
             const int rr = __builtin_ctz(rows);
             rows &= rows - 1;
             const int ii = ib + rr;
             const int lrow_u = lfirst[ii] + max(0, min(s, lnlev[ii] - 1));
             const int la_u = llen[lrow_u];
             la_max = max(la_max, la_u);
-            wide_build_pm<K>(pm + static_cast<size_t>(rr - g0) * tbl_entries, p.pm_stride,
-                             lcodes + static_cast<size_t>(lrow_u) * kRow, la_u, lane);
+            unsigned long long* tb = pm + static_cast<size_t>(rr - g0) * tbl_entries;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+              const int pos = lane + kWave * k;
+              if (pos < la_u) atomicOr(&tb[lcodes[static_cast<size_t>(lrow_u) * kRow + pos] * K + k], 1ull << lane);
+            }
           }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
           const unsigned long long* tbl = pm + static_cast<size_t>(mine ? r - g0 : 0) * tbl_entries;
           const int nchars = wave_max_i32(mine ? lbj : 0);
           const uint8_t* tptr = rcodes + static_cast<size_t>(mine ? rrow : rr0) * kRow;
@@ -485,18 +379,15 @@ __global__ __launch_bounds__(kBlock) void indel_levels_park_kernel(
               const uint4 v = tp[q];
               text[4 * q + 0] = v.x; text[4 * q + 1] = v.y; text[4 * q + 2] = v.z; text[4 * q + 3] = v.w;
             }
-            const int nwords = (nchars + 3) >> 2;
             unsigned long long v = ~0ull;
 #pragma unroll
-            for (int w = 0; w < 16; ++w) {
-              if (w < nwords) {
+            for (int g = 0; g < 8; ++g) {  // 8 code units per group, mask reads issued together (see the scan)
+              if (g * 8 < nchars) {
+                unsigned long long m[8];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                  const unsigned c = (text[w] >> (8 * q)) & 0xffu;
-                  const unsigned long long m = tbl[c];
-                  const unsigned long long u = v & m;
-                  v = lev_add64(v, u) | (v ^ u);
-                }
+                for (int q = 0; q < 8; ++q) m[q] = tbl[(text[2 * g + (q >> 2)] >> (8 * (q & 3))) & 0xffu];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v = lcs_step64(v, m[q]);
               }
             }
             got = 64 - __popcll(v);
@@ -514,6 +405,8 @@ __global__ __launch_bounds__(kBlock) void indel_levels_park_kernel(
       }
       if (run) {
         score += ratio * factor;
+        // steps still to come: histogram bound of the next level pair (exact upper bound; 1e-6 covers the
+        // float arithmetic of the bound and the rounding of the double sum)
         float rest = 0.0f;
         if (s < S) {
           const int t = s + 1;
@@ -522,36 +415,256 @@ __global__ __launch_bounds__(kBlock) void indel_levels_park_kernel(
         }
         alive = score + static_cast<double>(rest) + 1e-6 >= p.threshold;
       }
+      if (reg >= 0) {  // few pairs left with steps to go: hand them to the block's dense pass
+        const bool pending = alive && s >= s0 && s < S;
+        const unsigned long long who = __ballot(pending);
+        const int n = __popcll(who);
+        if (n > 0 && n <= p.park_max) {
+          const int have = reserve(reg, n);
+          if (have >= 0) {
+            if (pending) {
+              const int slot = (reg % kSub) * p.park_slots + have +
+                               __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(who >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(who), 0u));
+              park_score[slot] = score;
+              park_j[slot] = jr;
+              park_meta[slot] = r | ((s + 1) << 8);
+              alive = false;
+            }
+          }
+        }
+      }
     }
     if (active && alive && score >= p.threshold) emit_hit(hits, p.cap, count, score, lorig[i], rorig[jr]);
   };
 
-  int pb = 0;
+  // ---- this wave's tile against the batch rows [ib, ib + nrows); okbits bit r = the lane passes the
+  // category predicate for row ib + r; survivors go to park region `reg`
+  auto scan_batch = [&](int ib, int nrows, uint32_t okbits, uint32_t rows_ok, int reg) __attribute__((always_inline)) {
+    // ---- stage: heads of the batch's rows (lane = (row, step 1..3))
+    if (lane < nrows * 3) {
+      const int r = lane / 3, t = lane - 3 * r;
+      const int i = ib + r;
+      const int ll = lnlev[i], lf = lfirst[i];
+      const int lrow = lf + max(0, min(t + 1, ll - 1));
+      uint32_t h[NB];
+      if (use_hist) load_hist<NB>(lhist, lrow, h);
+      else
+#pragma unroll
+        for (int q = 0; q < NB; ++q) h[q] = 0u;
+      uint32_t* rec = head + lane * kHeadDwords;
+#pragma unroll
+      for (int q = 0; q < NB; ++q) rec[q] = h[q];
+      rec[NB] = static_cast<uint32_t>(llen[lrow]);
+      rec[NB + 1] = static_cast<uint32_t>(lrow);
+      rec[NB + 2] = static_cast<uint32_t>(ll);
+      rec[NB + 3] = static_cast<uint32_t>(lf);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- H: need[r][lane]
+    uint32_t live = 0;
+    for (uint32_t rows = rows_ok; rows;) {
+      const int r = __builtin_ctz(rows);
+      rows &= rows - 1;
+      const uint32_t* rec = head + r * 3 * kHeadDwords;
+      const int ll = wave_first(static_cast<int>(rec[NB + 2]));
+      const int S = max(ll, lr);
+      const float4 W = wtab[min(S, 65)];
+      uint32_t l1[3];
+      int la[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        la[t] = static_cast<int>(rec[t * kHeadDwords + NB]);
+        if (use_hist) {
+          uint32_t hl[NB];
+#pragma unroll
+          for (int q = 0; q < NB; ++q) hl[q] = rec[t * kHeadDwords + q];
+          l1[t] = hist_l1<NB>(hl, hb[t]);
+        } else {
+          l1[t] = t == 0 ? static_cast<uint32_t>(abs(la[0] - lb_t[0])) : 0u;
+        }
+      }
+      // alive after step 1  <=>  lcs / n1 + R >= thr,  R = (w2 + w3 + c) - w2 l2 / n2 - w3 l3 / n3;
+      // 2e-3 of an LCS unit covers the float rounding
+      const float i2 = __builtin_amdgcn_rcpf(static_cast<float>(max(la[1] + lb_t[1], 1)));
+      const float i3 = __builtin_amdgcn_rcpf(static_cast<float>(max(la[2] + lb_t[2], 1)));
+      const float x = W.x * static_cast<float>(l1[1]) * i2 + W.y * static_cast<float>(l1[2]) * i3;
+      const int n1 = la[0] + lb_t[0];
+      const float needf = static_cast<float>(n1) * (W.z + x) - 2e-3f;
+      const int nd = max(0, static_cast<int>(__builtin_ceilf(needf)));
+      const int m1 = (n1 - static_cast<int>(l1[0])) >> 1;  // LCS of step 1 <= m1 (<= min(la, lb))
+      const bool can = ((okbits >> r) & 1u) && nd <= m1;
+      need[r * kWave + lane] = can ? static_cast<uint16_t>(nd) : kDeadNeed;
+      live |= __any(can) ? (1u << r) : 0u;
+    }
+    if (!live) return;
+
+    // ---- step 1, wave-wide
+    stage_strings(ib, live, 1);
+    const int rrow = rrow0 + max(0, min(1, lr - 1));
+    if constexpr (K == 1) {
+      if (rrow != text_row) {  // step 1 reads the same right level for every batch
+        text_row = rrow;
+        const uint4* tp = reinterpret_cast<const uint4*>(rcodes + static_cast<size_t>(rrow) * 64);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint4 v = tp[q];
+          const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t c0 = w[e] & 0xffu, c1 = (w[e] >> 8) & 0xffu, c2 = (w[e] >> 16) & 0xffu, c3 = w[e] >> 24;
+            taddr[8 * q + 2 * e + 0] = (pm_base + 8 * c0) | ((pm_base + 8 * c1) << 16);
+            taddr[8 * q + 2 * e + 1] = (pm_base + 8 * c2) | ((pm_base + 8 * c3) << 16);
+          }
+        }
+        lb = rlen[rrow];
+      }
+    } else {
+      if (__any(rrow != text_row)) {  // the LDS image is rewritten by the whole wave
+        text_row = rrow;
+        wide_store_text<K>(wtext, rcodes + static_cast<size_t>(rrow) * kRow, lane);
+        lb = rlen[rrow];
+      }
+    }
+    const int nchars = wave_max_i32(valid ? lb : 0);
+    uint32_t over = 0;  // rows whose survivors were too many to park: their remaining steps follow below
+    for (uint32_t rows = live; rows;) {
+      const int r = __builtin_ctz(rows);
+      rows &= rows - 1;
+      const uint32_t* rec = head + r * 3 * kHeadDwords;
+      const int ll = wave_first(static_cast<int>(rec[NB + 2]));
+      const int S = max(ll, lr);
+      const int nd = need[r * kWave + lane];
+      const int la = wave_first(static_cast<int>(rec[NB]));
+      build_pm_staged(r, la);
+      int lcs;
+      if constexpr (K == 1) {
+        // opaque per row: otherwise the 64 unpacked addresses are hoisted out of the row loop into 64
+        // more VGPRs
+        asm volatile("" : "+v"(lowmask), "+v"(sh16));
+        // 8 code units per group: the 8 mask reads are issued together and their LDS latency overlaps the
+        // recurrence of the group before; positions past the text's end read the all-zero pad mask
+        if (la <= 32) {  // wave-uniform: 32-bit words, and / add / xor / or all issue at full rate
+          uint32_t v = ~0u;
+#pragma unroll
+          for (int g = 0; g < 8; ++g) {
+            if (g * 8 < nchars) {
+              uint32_t m[8];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                m[2 * q] = lev_lds_load<uint32_t>(taddr[4 * g + q] & lowmask);
+                m[2 * q + 1] = lev_lds_load<uint32_t>(taddr[4 * g + q] >> sh16);
+              }
+#pragma unroll
+              for (int q = 0; q < 8; ++q) v = lcs_step32(v, m[q]);
+            }
+          }
+          lcs = 32 - __popc(v);
+        } else {
+          unsigned long long v = ~0ull;
+#pragma unroll
+          for (int g = 0; g < 8; ++g) {
+            if (g * 8 < nchars) {
+              unsigned long long m[8];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                m[2 * q] = lev_lds_load<unsigned long long>(taddr[4 * g + q] & lowmask);
+                m[2 * q + 1] = lev_lds_load<unsigned long long>(taddr[4 * g + q] >> sh16);
+              }
+#pragma unroll
+              for (int q = 0; q < 8; ++q) v = lcs_step64(v, m[q]);
+            }
+          }
+          lcs = 64 - __popcll(v);
+        }
+      } else {
+        lcs = wide_lcs<K>(pm, wtext, nchars, lane, la);
+      }
+      const bool alive = nd != kDeadNeed && lcs >= nd;  // can still reach the threshold
+      if (!__any(alive)) continue;
+      const bool more = alive && S > 1;
+      if (__any(alive && !more)) {  // single-step pairs (both items have one level): final here
+        const double score = ratio_of(la, lb, lcs) * 0.5;
+        const bool hit = alive && !more && score >= p.threshold;
+        if (__any(hit)) {
+          if (hit) emit_hit(hits, p.cap, count, score, lorig[ib + r], jorig);
+        }
+      }
+      const unsigned long long who = __ballot(more);
+      if (who == 0ull) continue;
+      const int n = __popcll(who);
+      int have = -1;
+      if (n <= p.park_max) have = reserve(reg, n);
+      if (have >= 0) {
+        // parked with the LCS itself (bit 16 of meta): the dense pass turns it into the score -- the ratio
+        // table is a gather from L2 whose latency would be paid per row here
+        if (more) {
+          const int slot = (reg % kSub) * p.park_slots + have +
+                           __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(who >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(who), 0u));
+          park_score[slot] = __longlong_as_double(static_cast<long long>(lcs));
+          park_j[slot] = jc;
+          park_meta[slot] = r | (2 << 8) | 0x10000;
+        }
+      } else {  // dense enough (or the park is full): the row's remaining steps are scored by this wave itself
+        need[r * kWave + lane] = more ? static_cast<uint16_t>(lcs) : kDeadNeed;
+        over |= 1u << r;
+      }
+    }
+    if (over) {
+      text_row = -1;  // the text image's registers are free for the dense steps
+      for (uint32_t rows = over; rows;) {
+        const int r = __builtin_ctz(rows);
+        rows &= rows - 1;
+        const int lcs1 = need[r * kWave + lane];
+        dense_steps(ib, nrows, lcs1 != kDeadNeed, r, jc, 2, __longlong_as_double(static_cast<long long>(lcs1)), true, reg);
+      }
+    }
+  };
+
+  int pb = 0;  // parity of the super-batch: which half of the park counters is in use
   for (unsigned long long cats = cats_block; cats;) {  // the same sequence in every wave of the block
     const int c = __builtin_ctzll(cats);
     cats &= cats - 1;
     const int a = partitioned ? max(i0, lsegstart[c]) : i0;
     const int b = partitioned ? min(i1, lsegstart[c + 1]) : i1;
     const unsigned long long lower = (1ull << c) - 1ull;
-    for (int ib = a; ib < b; ib += kBatch) {
-      const int nrows = min(kBatch, b - ib);
-      uint32_t okbits = 0, rows_ok = 0;
-      for (int r = 0; r < nrows; ++r) {
-        const uint64_t cl = (p.cat_mode != NSM_CAT_NONE) ? lcat[ib + r] : 0ull;
-        bool ok = valid;
-        if (partitioned) ok = ok && myseg == c && ((cl & catr & lower) == 0ull);
-        else if (p.cat_mode != NSM_CAT_NONE) ok = ok && category_match(cl, catr, p.cat_mode);
-        okbits |= ok ? (1u << r) : 0u;
-        rows_ok |= __any(ok) ? (1u << r) : 0u;
+    for (int sb = a; sb < b; sb += kBatch * kSub) {
+      for (int g = 0; g < kSub; ++g) {
+        const int ib = sb + g * kBatch;
+        if (ib >= b) break;
+        const int nrows = min(kBatch, b - ib);
+        uint32_t okbits = 0, rows_ok = 0;
+        for (int r = 0; r < nrows; ++r) {
+          const uint64_t cl = (p.cat_mode != NSM_CAT_NONE) ? lcat[ib + r] : 0ull;
+          bool ok = valid;
+          if (partitioned) ok = ok && myseg == c && ((cl & catr & lower) == 0ull);
+          else if (p.cat_mode != NSM_CAT_NONE) ok = ok && category_match(cl, catr, p.cat_mode);
+          okbits |= ok ? (1u << r) : 0u;
+          rows_ok |= __any(ok) ? (1u << r) : 0u;
+        }
+        if (rows_ok) scan_batch(ib, nrows, okbits, rows_ok, pb * kSub + g);
       }
-      if (rows_ok) scan_batch(ib, nrows, okbits, rows_ok, pb);
-      __syncthreads();  // every tile's survivors of this batch are parked
-      const int n_p = min(s_cnt[pb], s_valid[pb]);
-      if (threadIdx.x == 0) {  // the other parity's counters were consumed before the previous batch's last barrier
-        s_cnt[pb ^ 1] = 0;
-        s_valid[pb ^ 1] = p.park_slots;
+      __syncthreads();  // every tile's survivors of this super-batch are parked
+      text_row = -1;    // the text image does not outlive the super-batch: its registers are free in the dense pass
+      if (threadIdx.x < kSub) {  // the other parity's counters were consumed before the previous super-batch's last barrier
+        s_cnt[(pb ^ 1) * kSub + threadIdx.x] = 0;
+        s_valid[(pb ^ 1) * kSub + threadIdx.x] = p.park_slots;
       }
-      for (int base = wave * kWave; base < n_p; base += waves * kWave) finish_pass(ib, nrows, base, n_p);
+      for (int g = wave; g < kSub; g += waves) {
+        const int ib = sb + g * kBatch;
+        if (ib >= b) break;
+        const int n_p = min(s_cnt[pb * kSub + g], s_valid[pb * kSub + g]);
+        for (int base = 0; base < n_p; base += kWave) {
+          const bool active = base + lane < n_p;
+          const int slot = g * p.park_slots + (active ? base + lane : base);
+          const int meta = park_meta[slot];
+          dense_steps(ib, min(kBatch, b - ib), active, meta & 0xff, park_j[slot], (meta >> 8) & 0xff, park_score[slot],
+                      (meta & 0x10000) != 0, -1);
+        }
+      }
       __syncthreads();  // the park has been read
       pb ^= 1;
     }

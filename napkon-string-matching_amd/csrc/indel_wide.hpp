@@ -108,22 +108,50 @@ __device__ __forceinline__ void add_chain(const unsigned long long (&v)[W], cons
 template <int K, int W, bool EARLY>
 __device__ __forceinline__ int wide_lcs_words(const unsigned long long* pm, const uint32_t* text, int nchars,
                                               int lane, int lb, int need) {
+  // Software-pipelined: the text dword of iteration w + 1 (W <= 2: w + 2) and, for W <= 2, the masks of
+  // iteration w + 1 are requested before the recurrence of iteration w runs, so the two dependent LDS
+  // latencies of a step (text dword -> mask words) overlap the arithmetic instead of stalling it
+  // (measured on the levels kernels: one LDS round trip per dependent step left the waves waiting ~100
+  // cycles per 2-4 code units).  Reads past the last text dword are clamped to it (results unused).
+  constexpr bool kDeep = W <= 2;
   unsigned long long v[W];
 #pragma unroll
   for (int k = 0; k < W; ++k) v[k] = ~0ull;
   const int nw = (nchars + 3) >> 2;
-  for (int w = 0; w < nw; ++w) {
-    const uint32_t word = text[w * kWave + lane];
+  if (nw == 0) return 0;
+  auto load_masks = [&](uint32_t word, unsigned long long (&m)[4][W]) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      const unsigned c = (word >> (8 * b)) & 0xffu;
-      const unsigned long long* e = pm + c * K;
+      const unsigned long long* e = pm + ((word >> (8 * b)) & 0xffu) * K;
+#pragma unroll
+      for (int k = 0; k < W; ++k) m[b][k] = e[k];
+    }
+  };
+  uint32_t w_next = text[lane];                            // dword of iteration 0
+  uint32_t w_next2 = text[min(1, nw - 1) * kWave + lane];  // dword of iteration 1
+  unsigned long long m_cur[4][W];
+  if (kDeep) load_masks(w_next, m_cur);
+  for (int w = 0; w < nw; ++w) {
+    const uint32_t word = w_next;
+    w_next = w_next2;
+    w_next2 = text[min(w + 2, nw - 1) * kWave + lane];
+    unsigned long long m_nx[4][W];
+    if (kDeep) load_masks(w_next, m_nx);
+    else load_masks(word, m_cur);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
       unsigned long long u[W], t[W];
 #pragma unroll
-      for (int k = 0; k < W; ++k) u[k] = v[k] & e[k];
+      for (int k = 0; k < W; ++k) u[k] = v[k] & m_cur[b][k];
       add_chain<W>(v, u, t);
 #pragma unroll
       for (int k = 0; k < W; ++k) v[k] = t[k] | (v[k] ^ u[k]);
+    }
+    if (kDeep) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int k = 0; k < W; ++k) m_cur[b][k] = m_nx[b][k];
     }
     if (EARLY && (w & 1)) {
       int ones = 0;

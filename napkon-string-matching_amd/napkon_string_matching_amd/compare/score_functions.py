@@ -22,7 +22,16 @@ import torch
 
 from .. import grid, tables
 
-_NON_WORD = re.compile(r"\W", re.UNICODE)
+_NON_WORD = re.compile(r"\W", re.UNICODE)        # keeps "_": what rapidfuzz 2.1's pure-Python fallback does
+_NON_ALNUM = re.compile(r"[\W_]", re.UNICODE)    # blanks "_" too: "non alphanumeric", the compiled implementation
+
+# How ``default_process`` treats "_" -- the one point where rapidfuzz 2.1's two implementations of it differ:
+# the C++ one (what a pip-installed wheel runs, and what its documentation describes: "removing all non
+# alphanumeric characters") blanks it, the pure-Python fallback (``re.sub(r"(?ui)\W", " ", s)``) keeps it.
+# rapidfuzz is not installable offline, so this cannot be pinned against the pinned version; the switch is
+# explicit instead of buried in a regex.  Synthetic corpora only use ``[a-z0-9 ]``, a fixed point of both.
+UNDERSCORE_POLICIES = ("blank", "keep")
+UNDERSCORE_POLICY = "blank"
 
 Operand = Union[str, List[str]]
 
@@ -40,10 +49,14 @@ def join_sorted(value: Sequence[str]) -> str:
     return " ".join(sorted(value, key=str.lower))
 
 
-def default_process(text: str) -> str:
+def default_process(text: str, underscore: str = None) -> str:
     """rapidfuzz 2.x ``utils.default_process`` (applied by ``fuzz.QRatio`` by default in the
-    pinned 2.1 line): non-word code points -> blank, strip, lower-case."""
-    return _NON_WORD.sub(" ", text).strip().lower()
+    pinned 2.1 line): non-alphanumeric code points -> blank, strip, lower-case.  ``underscore``:
+    "blank" or "keep" (default: the module's ``UNDERSCORE_POLICY``)."""
+    policy = UNDERSCORE_POLICY if underscore is None else underscore
+    if policy not in UNDERSCORE_POLICIES:
+        raise ValueError(f"underscore policy must be one of {UNDERSCORE_POLICIES}")
+    return (_NON_ALNUM if policy == "blank" else _NON_WORD).sub(" ", text).strip().lower()
 
 
 def fuzzy_operand(value: Operand) -> str:

@@ -10,10 +10,8 @@ that lives in rapidfuzz 2.1.x, the published behaviour of ``fuzz.QRatio``:
 
 ``fuzzy_match`` is *parity unpinned* (see oracle/__init__.py).
 """
-import re
 from typing import List, Sequence, Union
 
-_NON_WORD = re.compile(r"\W", re.UNICODE)
 
 
 def intersection_vs_union(left: Union[List[str], str], right: Union[List[str], str]) -> float:
@@ -32,16 +30,28 @@ def join_sorted(value: Sequence[str]) -> str:
     return " ".join(sorted(value, key=str.lower))
 
 
-def default_process(text: str) -> str:
-    """rapidfuzz 2.x ``utils.default_process``.
+UNDERSCORE_POLICY = "blank"  # mirrors the product's switch (compare/score_functions.py); see default_process
 
-    Every non-word code point becomes a blank, the result is stripped and
-    lower-cased (rapidfuzz/utils_py.py of the 2.1 line: ``re.sub(r"(?ui)\\W", " ", s)``
-    then ``.strip().lower()``).  Whether the compiled variant also keeps ``_`` could
-    not be checked offline; the synthetic corpora of this build only use
-    ``[a-z0-9 ]`` which is a fixed point of both readings.
+
+def default_process(text: str, underscore: str = None) -> str:
+    """rapidfuzz 2.x ``utils.default_process``: every non-alphanumeric code point becomes a blank, the
+    result is stripped and lower-cased.
+
+    Restated PER CODE POINT with ``str.isalnum`` -- on purpose not the regular expression the product
+    uses, so that the parity test compares two implementations and not one pattern with itself.  The
+    two implementations inside rapidfuzz 2.1 differ on "_" (C++: blank; pure-Python fallback
+    ``re.sub(r"(?ui)\\W", " ", s)``: kept, because ``\\w`` is ``isalnum() or "_"``); ``underscore`` selects
+    the reading ("blank" / "keep"), default = the compiled implementation's.  Not checkable offline:
+    fuzzy_match stays *parity unpinned*.
     """
-    return _NON_WORD.sub(" ", text).strip().lower()
+    policy = UNDERSCORE_POLICY if underscore is None else underscore
+    if policy not in ("blank", "keep"):
+        raise ValueError("underscore policy must be 'blank' or 'keep'")
+    keep_underscore = policy == "keep"
+    out = []
+    for ch in text:
+        out.append(ch if (ch.isalnum() or (keep_underscore and ch == "_")) else " ")
+    return "".join(out).strip().lower()
 
 
 def lcs_length(a: str, b: str) -> int:
@@ -75,6 +85,16 @@ def indel_ratio_from_lcs(len_a: int, len_b: int, lcs: int) -> float:
     norm_dist = dist / maximum
     norm_sim = 1.0 - norm_dist
     return (norm_sim * 100) / 100
+
+
+def ratio(left: str, right: str) -> float:
+    """``rapidfuzz.fuzz.ratio`` (no processor) in [0, 100]: the normalized Indel similarity of the strings
+    as they are."""
+    if not left or not right:
+        return 0
+    maximum = len(left) + len(right)
+    dist = maximum - 2 * lcs_length(left, right)
+    return (1.0 - dist / maximum) * 100
 
 
 def q_ratio(left: str, right: str) -> float:

@@ -24,6 +24,7 @@ import random
 import sys
 import tempfile
 import types
+import zlib
 from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
@@ -336,7 +337,7 @@ def main():
         ("rand_30x40", 30, 40, 0.05, False, 7),
         ("rand_40x30_categories", 40, 30, 0.05, True, 0),
     ]:
-        r2 = random.Random(hash(name) % 1000 + 5)
+        r2 = random.Random(zlib.crc32(name.encode()) % 1000 + 5)  # not hash(): str hashes change per process
         left, right = cohort(r2, "hap", n, vocab=40, max_tokens=5, none_every=none_every), cohort(r2, "suep", m, vocab=40, max_tokens=5)
         bl = {f"b{k}": {"hap": [left[r2.randrange(n)]["Identifier"]], "suep": [right[r2.randrange(m)]["Identifier"] for _ in range(2)]} for k in range(6)}
         kw = dict(score_func="intersection_vs_union", compare_column="Tokens", left_name="hap", right_name="suep", filter_categories=cats)

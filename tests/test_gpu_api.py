@@ -35,15 +35,44 @@ def test_intersection_vs_union_golden(golden):
         _check(case, join_sorted, *case["args"])
 
 
-def test_fuzzy_match_scalar_against_oracle():
-    from napkon_string_matching_amd.compare.score_functions import fuzzy_match
+def test_fuzzy_match_scalar_against_oracle(monkeypatch):
+    """Scalar plugin calls and one batched grid against the oracle, under both readings of "_" in
+    default_process (the product restates it as a regex, the oracle per code point)."""
+    import random
+
+    from napkon_string_matching_amd.compare import score_functions as sf
     from oracle import score_functions as osf
 
     cases = [("kitten", "sitting"), ("Dialyse", "Dialyse nach Entlassung"), ("this is a test", "THIS is a test!"),
              ("abc", ""), ("", ""), (["b", "A"], "a b"), (["Zeta", "alpha", "Beta"], ["beta", "ALPHA"]),
-             ("a_b-c", "a b c")]
-    for a, b in cases:
-        assert abs(fuzzy_match(a, b) - osf.fuzzy_match(a, b)) <= 1e-6
+             ("a_b-c", "a b c"), ("Größe_(cm)", "groesse cm"), ("x_1", "X 1"), ("__", "_")]
+    rng = random.Random(11)
+    pool = list("abcdeXYZ0123 _-.,;!?()/") + list("äöüÄÖÜßéñ") + list("αβД中٣")
+    texts = ["".join(rng.choice(pool) for _ in range(rng.randint(0, 30))) for _ in range(60)]
+    for policy in ("blank", "keep"):
+        monkeypatch.setattr(sf, "UNDERSCORE_POLICY", policy)
+        monkeypatch.setattr(osf, "UNDERSCORE_POLICY", policy)
+        for a, b in cases:
+            assert abs(sf.fuzzy_match(a, b) - osf.fuzzy_match(a, b)) <= 1e-6, (policy, a, b)
+        got = {(i, j): sc for sc, i, j in sf.fuzzy_match.raw_grid(texts, texts[::-1], float("-inf")).as_tuples()}
+        assert len(got) == len(texts) ** 2
+        for i, a in enumerate(texts):
+            for j, b in enumerate(texts[::-1]):
+                want = osf.fuzzy_match(a, b)
+                assert got[i, j] == want and abs(got[i, j] - want) <= 1e-6, (policy, a, b)
+    monkeypatch.setattr(sf, "UNDERSCORE_POLICY", "keep")
+    monkeypatch.setattr(osf, "UNDERSCORE_POLICY", "keep")
+    assert sf.fuzzy_match("a_b", "a b") < 1.0
+    monkeypatch.setattr(sf, "UNDERSCORE_POLICY", "blank")
+    assert sf.fuzzy_match("a_b", "a b") == 1.0
+    # rapidfuzz's own published numbers (see tests/test_oracle_golden.py::test_rapidfuzz_published_answers),
+    # through the RAW kernel on the unprocessed strings
+    from napkon_string_matching_amd import grid, tables
+    import torch
+
+    lt, rt = tables.encode_strings(["this is a test", "lewenstein"], ["this is a test!", "levenshtein"], torch.device("cuda:0"))
+    raw = {(i, j): sc for sc, i, j in grid.indel_raw_grid(lt, rt, -1.0).as_tuples()}
+    assert abs(raw[0, 0] * 100 - 96.55172413793103) <= 1e-9 and abs(raw[1, 1] - 0.8571428571428572) <= 1e-15
 
 
 def test_compare_terms_golden(golden):

@@ -129,5 +129,45 @@ def test_fuzzy_known_answers():
     assert osf.fuzzy_match("abc", "") == 0.0
     assert osf.fuzzy_match("", "") == 0.0
     assert osf.fuzzy_match(["b", "A"], "a b") == 1.0
-    assert osf.default_process("  Hello, World!_x ") == "hello  world _x"
+    assert osf.default_process("  Hello, World!_x ", underscore="keep") == "hello  world _x"
+    assert osf.default_process("  Hello, World!_x ", underscore="blank") == "hello  world  x"
+    assert osf.default_process("  Hello, World!_x ") == osf.default_process("  Hello, World!_x ", underscore=osf.UNDERSCORE_POLICY)
     assert osf.lcs_length("AGGTAB", "GXTXAYB") == 4
+
+
+def test_rapidfuzz_published_answers():
+    """Values rapidfuzz publishes for the 2.x line (fuzzy_match's arithmetic lives there, pinned ~=2.1.4 by the
+    reference's pyproject.toml:17; the package is not installable offline, so these are the only numbers of
+    its own that can anchor the restatement):
+      README, "Simple Ratio":  fuzz.ratio("this is a test", "this is a test!") -> 96.55...  (= 100 * 28 / 29)
+      rapidfuzz.distance.Indel docs:  distance("lewenstein", "levenshtein") -> 3, similarity -> 18,
+        normalized_distance -> 0.14285714285714285, normalized_similarity -> 0.8571428571428572
+      README, "Process"/QRatio default processor: upper case and punctuation do not matter."""
+    assert osf.ratio("this is a test", "this is a test!") == pytest.approx(96.55172413793103, abs=1e-9)
+    a, b = "lewenstein", "levenshtein"
+    lcs = osf.lcs_length(a, b)
+    assert len(a) + len(b) - 2 * lcs == 3 and lcs * 2 == 18
+    assert osf.indel_ratio_from_lcs(len(a), len(b), lcs) == pytest.approx(0.8571428571428572, abs=1e-15)
+    assert 1.0 - osf.indel_ratio_from_lcs(len(a), len(b), lcs) == pytest.approx(0.14285714285714285, abs=1e-15)
+    assert osf.q_ratio("this is a test", "THIS is a test!") == 100.0
+
+
+def test_default_process_two_implementations_agree():
+    """The product restates default_process as a regular expression, the oracle per code point with
+    str.isalnum: compared here on strings with "_", punctuation, upper case, non-ASCII letters and digits,
+    under BOTH readings of the underscore (rapidfuzz 2.1's C++ and pure-Python implementations differ there)."""
+    import random
+
+    from napkon_string_matching_amd.compare import score_functions as sf
+
+    rng = random.Random(5)
+    pool = list("abcXYZ019 _-.,;:!?()[]/\\'\"\t\n") + list("äöüÄÖÜßéèñçøÅ") + list("αβγДЖ中文٣४①²½") + ["\u00a0", "\u2003", "İ", "ǅ"]
+    samples = ["", "_", "__a__", "a_b-c", "  Hello, World!_x ", "Größe_(cm)", "İstanbul_2", "x\u00a0y", "a\tb_c\n"]
+    samples += ["".join(rng.choice(pool) for _ in range(rng.randint(0, 24))) for _ in range(3000)]
+    for policy in ("blank", "keep"):
+        for text in samples:
+            assert sf.default_process(text, underscore=policy) == osf.default_process(text, underscore=policy), (policy, text)
+    assert sf.UNDERSCORE_POLICY == osf.UNDERSCORE_POLICY
+    assert sf.default_process("a_b") == ("a b" if sf.UNDERSCORE_POLICY == "blank" else "a_b")
+    with pytest.raises(ValueError):
+        sf.default_process("x", underscore="maybe")
