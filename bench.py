@@ -19,18 +19,35 @@ cohorts, 4 levels, 32 categories, filter_categories, both score functions back t
 levels-mode kernels, left rows of every cohort pair divided over the ranks: "strong").
 
 The JSON line carries, besides the driver's contract fields:
-  roofline      dominant kernel; achieved = algorithmic bytes (128 B per pair) per
-                launch / average kernel duration measured with HIP events on the launch stream
-  exhaustive    the same grid with the exact prune disabled (every pair's matrix evaluated)
-  limiter       the pruned kernel against its real bound, the VALU issue rate of the per-row filter
-  cpu_baseline  the oracle's restatement of the reference's Python loop, 1 core, bounded sample
+  roofline      dominant kernel against the bound it can actually approach, the VALU issue rate (this path
+                keeps its operands on chip: measured HBM traffic is < 2 % of peak, and the "algorithmic bytes"
+                of SURVEY.md 8d -- 128 B per pair -- exceed what any kernel moves by two orders of magnitude,
+                so a fraction of HBM peak built on them is > 1 and says nothing).
+                  achieved = VALU wave-instructions per launch (SQ_INSTS_VALU, profiles/pmc_<workload>.json,
+                             collected by tools/pmc_collect.sh) / the kernel's duration measured here with HIP
+                             events on the launch stream
+                  peak     = 1024 SIMDs x 2.4 GHz / 2 cycles (a wave64 VALU op occupies a SIMD-32 for >= 2 cycles)
+                  frac     = achieved / peak  (<= 1 by construction; half-rate VOP3 ops cap it near 0.5)
+                beside it: frac_pmc (the same ratio from the profile's own cycle count), valu_busy_quadcycles
+                (SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles: counts a quad-cycle per instruction, can exceed 1),
+                traffic (HBM bytes per launch, FETCH_SIZE x 2 + WRITE_SIZE) with hbm_frac, the algorithmic and
+                compulsory byte counts, and the profile's stamp (git head, hash of csrc/ -- a stale profile shows).
+  exhaustive    the same grid with the exact prune disabled (every pair's full comparison evaluated)
+  cpu_baseline  the oracle's restatement of the reference's loop, 1 core, bounded sample
+  c4            (N > 1 only) BASELINE configs[3], 1M x 1M strong-scaled over the ranks, after the headline
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
 import time
 from pathlib import Path
+
+# ROCr reads HSA_* at hsa_init: this must be in the environment before torch touches the GPU (the host driver
+# only supports dmabuf IPC; without it RCCL's P2P setup fails with hipIpcGetMemHandle: invalid argument)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 
 ROOT = Path(__file__).resolve().parent
 for _p in (str(ROOT), str(ROOT / "napkon-string-matching_amd")):
@@ -38,6 +55,7 @@ for _p in (str(ROOT), str(ROOT / "napkon-string-matching_amd")):
         sys.path.insert(0, _p)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2  # G wave64-instructions/s: 1024 SIMD-32 x 2.4 GHz, >= 2 cycles per instruction
 BYTES_PER_PAIR = 128  # two 64-byte operand rows
 
 
@@ -55,18 +73,24 @@ def parse_args():
     ap.add_argument("--capacity", type=int, default=1 << 13)
     ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
                     help="gloo = CPU-staged rehearsal of the N > 1 path (e.g. 2 ranks sharing one GPU)")
+    ap.add_argument("--allow-gloo", action="store_true",
+                    help="if RCCL cannot be brought up on every rank, run the exchange staged through host memory "
+                         "instead of exiting non-zero (the JSON's config.exchange says which one ran)")
+    ap.add_argument("--no-c4", action="store_true", help="N > 1: skip the extra configs[3] (1M x 1M strong) run")
     return ap.parse_args()
 
 
 class Workload:
     """Operand tables in HBM + the launch closure of one workload."""
 
-    def __init__(self, name, rank, world, rows, device, right_rows=0, threshold=None):
+    def __init__(self, name, comm, rows, device, right_rows=0, threshold=None):
         import numpy as np
         import torch
 
         from napkon_string_matching_amd import _lib, synthetic, tables
 
+        rank, world = comm.rank, comm.world
+        self.comm = comm
         self.name = name
         self.lib = _lib.load()
         self.flag_prune = _lib.FLAG_PRUNE
@@ -90,7 +114,7 @@ class Workload:
                 right_planted = None
             self.host = (left, right, right_planted)
             self.left_np = left
-            right = self._share_right(right_planted, right, device, world)
+            right = comm.broadcast_numpy(right_planted, right)
             self.right_np = right
             orig = np.arange(n, dtype=np.int32) + rank * n
             t_enc = time.perf_counter()
@@ -100,6 +124,7 @@ class Workload:
             self.encode_h2d_seconds = time.perf_counter() - t_enc
             self.launch_fn = self.lib.nsm_jaccard_raw_grid
             self.kernel = "jaccard_raw_kernel<16>"
+            self.kernel_match, self.kernel_match_exhaustive = "jaccard_raw_kernel<16, true>", "jaccard_raw_kernel<16, false>"
             self.dtype = "int32"
             self.label = (f"{name.upper()}: {n}x{m} token-id sets/GPU (Poisson(8) ids, W=16), intersection_vs_union RAW, "
                           f"threshold {self.threshold}")
@@ -123,7 +148,9 @@ class Workload:
             li, ls, ri, rs = self.term_tables
             self.left, self.right = ls, rs
             self.term_structs = (li.struct(), ls.struct(), ri.struct(), rs.struct())
-            self.kernel = f"indel_levels_kernel<{ls.stride // 64}>"
+            self.kernel = f"indel_levels_park_kernel<{ls.stride // 64}>"
+            self.kernel_match = f"indel_levels_park_kernel<{ls.stride // 64}>"
+            self.kernel_match_exhaustive = f"indel_levels_kernel<{ls.stride // 64}>"
             self.dtype = "u64"
             lens = [len(s) for it in self.left_np for s in it[1:]]
             self.label = (f"TERM: {n}x{m} Term-shaped items/GPU (3-5 entries -> 3-5 suffix-nested levels, joined level strings "
@@ -140,7 +167,7 @@ class Workload:
                 packed = np.concatenate([rp[0], rp[1].astype(np.int32).view(np.uint8).reshape(m, 4)], axis=1)
             else:
                 packed = None
-            packed = self._share_right(packed, np.zeros((m, 68), np.uint8), device, world)
+            packed = comm.broadcast_numpy(packed, np.zeros((m, 68), np.uint8))
             rc, rl = packed[:, :64].copy(), packed[:, 64:].copy().view(np.int32).reshape(m)
             self.left_np, self.right_np = left, (rc, rl)
             orig = np.arange(n, dtype=np.int32) + rank * n
@@ -152,6 +179,7 @@ class Workload:
             self.encode_h2d_seconds = time.perf_counter() - t_enc
             self.launch_fn = self.lib.nsm_indel_raw_grid
             self.kernel = "indel_raw_kernel"
+            self.kernel_match, self.kernel_match_exhaustive = "indel_raw_kernel<true>", "indel_raw_kernel<false>"
             self.dtype = "u64"
             self.label = f"C3: {n}x{m} strings/GPU (len U[16,64], 37 symbols), fuzzy_match RAW, threshold {self.threshold}"
         self.n, self.m = n, m
@@ -160,21 +188,6 @@ class Workload:
         if name == "term":  # both items' level strings (mean levels x row stride)
             li, ls, ri, rs = self.term_tables
             self.bytes_per_pair = int(round((ls.n / max(1, li.n) + rs.n / max(1, ri.n)) * ls.stride))
-
-    @staticmethod
-    def _share_right(planted, like, device, world):
-        """The right side is replicated: rank 0's array is broadcast over RCCL."""
-        import torch
-
-        if world == 1:
-            return planted
-        import torch.distributed as dist
-
-        t = torch.from_numpy(planted if planted is not None else like.copy())
-        if dist.get_backend() == "nccl":
-            t = t.to(device)
-        dist.broadcast(t, src=0)
-        return t.cpu().numpy()
 
     def launch(self, buf, stream, prune=True):
         from napkon_string_matching_amd import _lib
@@ -196,19 +209,160 @@ class Workload:
         )
 
 
-def gather_hits(buf, out, world, device, async_op=False):
-    """all-gatherv of the (score, i, j) hits.  RCCL has no native gatherv; the hit buffer carries its
-    own counter in a trailing record (grid.HitBuffer), so ONE all-gather of the max-padded storage
-    moves records and counts together.  Returns the work handle when ``async_op``."""
-    import torch
-    import torch.distributed as dist
+class Comm:
+    """Process groups of an N > 1 run.  The default group is gloo (control plane: barriers, agreement, host-side
+    numbers); the device-resident exchange runs on an RCCL group that is brought up and probed on EVERY rank, and
+    the ranks agree on the outcome over gloo before anyone uses it -- a rank-local fallback would leave the ranks
+    split over two backends and the next collective hanging."""
 
-    if dist.get_backend() != "nccl":  # gloo rehearsal: stage through host memory
-        host = torch.empty((world * buf.storage.shape[0], 2), dtype=buf.storage.dtype)
-        dist.all_gather_into_tensor(host, buf.storage.cpu())
-        out.copy_(host.view_as(out))
-        return None
-    return dist.all_gather_into_tensor(out.view(-1, 2), buf.storage, async_op=async_op)
+    def __init__(self, args, rank, world, device):
+        import torch
+
+        self.rank, self.world, self.device = rank, world, device
+        self.dist = None
+        self.dev_group = None
+        self.exchange = None
+        self.rccl_ranks = None
+        if world == 1:
+            return
+        from datetime import timedelta
+
+        import torch.distributed as dist
+
+        self.dist = dist
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=600))
+        if args.dist_backend == "nccl":
+            ok, err = 1, ""
+            try:  # one tiny collective up front so that a broken transport shows here, not mid-run
+                group = dist.new_group(backend="nccl", timeout=timedelta(seconds=180))
+                probe = torch.ones(1, device=device)
+                dist.all_reduce(probe, group=group)
+                torch.cuda.synchronize(device)
+                self.rccl_ranks = int(probe.item())
+                if self.rccl_ranks != world:
+                    raise RuntimeError(f"RCCL all-reduce saw {self.rccl_ranks} ranks, expected {world}")
+                self.dev_group = group
+            except Exception as exc:  # noqa: BLE001 -- reported below, after the ranks have agreed
+                ok, err = 0, f"{type(exc).__name__}: {exc}"
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # gloo: every rank learns whether ALL ranks are up
+            if int(flag.item()) == 0:
+                self.dev_group = None
+                if err:
+                    print(f"[bench] rank {rank}: RCCL unavailable ({err})", file=sys.stderr)
+                if not args.allow_gloo:
+                    dist.barrier()
+                    dist.destroy_process_group()
+                    raise SystemExit("bench.py: RCCL could not be brought up on every rank; pass --allow-gloo to "
+                                     "measure the host-staged exchange instead (that is NOT an RCCL number)")
+                if rank == 0:
+                    print("[bench] --allow-gloo: the hit exchange is staged through host memory", file=sys.stderr)
+        self.exchange = "rccl all-gather" if self.dev_group is not None else "gloo, staged through host memory"
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def max_seconds(self, dt):
+        if self.dist is None:
+            return dt
+        import torch
+
+        t = torch.tensor([dt], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def broadcast_numpy(self, array, like):
+        """Rank 0's array on every rank (the replicated right side)."""
+        import torch
+
+        if self.dist is None:
+            return array
+        t = torch.from_numpy(array if array is not None else like.copy())
+        if self.dev_group is not None:
+            t = t.to(self.device)
+            self.dist.broadcast(t, src=0, group=self.dev_group)
+            return t.cpu().numpy()
+        self.dist.broadcast(t, src=0)
+        return t.numpy()
+
+    def gather_hits(self, buf, out, async_op=False):
+        """all-gatherv of the (score, i, j) hits.  RCCL has no native gatherv; the hit buffer carries its own
+        counter in a trailing record (grid.HitBuffer), so ONE all-gather of the max-padded storage moves records
+        and counts together.  Returns the work handle when ``async_op``."""
+        import torch
+
+        if self.dev_group is None:  # gloo: stage through host memory
+            host = torch.empty((self.world * buf.storage.shape[0], 2), dtype=buf.storage.dtype)
+            self.dist.all_gather_into_tensor(host, buf.storage.cpu())
+            out.copy_(host.view_as(out))
+            return None
+        return self.dist.all_gather_into_tensor(out.view(-1, 2), buf.storage, group=self.dev_group, async_op=async_op)
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+def csrc_hash():
+    """sha256 (16 hex digits) of the kernel sources: profiles are stamped with it (tools/pmc_to_json.py)."""
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "napkon-string-matching_amd" / "csrc").glob("*.h*")):
+        if f.suffix in (".hip", ".hpp"):
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def valu_roofline(profile_name, kernel_match, kernel_label, kernel_ms, launches_per_ms_sample, algorithmic_bytes,
+                  compulsory_bytes, default_shape=True):
+    """The roofline object (see the module docstring).  ``kernel_ms`` = duration of ``launches_per_ms_sample``
+    launches of the dominant kernel, measured by the caller with HIP events."""
+    roof = {
+        "bound": "valu_issue",
+        "kernel": kernel_label,
+        "achieved": None,
+        "peak": VALU_PEAK_GINST,
+        "unit": "G wave64 VALU instructions/s",
+        "frac": None,
+        "traffic": None,
+        "kernel_ms": kernel_ms,
+        "algorithmic_bytes_per_launch": algorithmic_bytes,
+        "compulsory_hbm_bytes_per_launch": compulsory_bytes,
+        "effective_GBps_of_algorithmic_bytes": algorithmic_bytes * launches_per_ms_sample / (kernel_ms * 1e-3) / 1e9,
+    }
+    pfile = ROOT / "profiles" / f"pmc_{profile_name}.json"
+    if not default_shape:  # --rows / --right-rows / --threshold: the profile's instruction counts are another grid's
+        roof["profile"] = "not applicable: the workload's shape was overridden on the command line"
+        return roof
+    if not pfile.exists():
+        roof["profile"] = f"{pfile.name} missing: run tools/pmc_collect.sh on the GPU box"
+        return roof
+    prof = json.loads(pfile.read_text())
+    entry = next((v for k, v in prof["kernels"].items() if kernel_match in k), None)
+    if entry is None:
+        roof["profile"] = f"{pfile.name} has no kernel matching {kernel_match!r}"
+        return roof
+    c = entry["counters"]
+    insts = c["SQ_INSTS_VALU"] * launches_per_ms_sample
+    roof["achieved"] = insts / (kernel_ms * 1e-3) / 1e9
+    roof["frac"] = roof["achieved"] / VALU_PEAK_GINST
+    roof["frac_pmc"] = entry.get("valu_issue_frac")
+    roof["valu_busy_quadcycles"] = entry.get("valu_busy_frac")
+    roof["salu_issue_frac"] = entry.get("salu_issue_frac")
+    roof["lds_busy_frac"] = entry.get("lds_busy_frac")
+    roof["valu_instructions_per_launch"] = c["SQ_INSTS_VALU"]
+    if "hbm_bytes_per_launch" in entry:
+        roof["traffic"] = entry["hbm_bytes_per_launch"] * launches_per_ms_sample
+        roof["hbm_frac"] = roof["traffic"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
+    roof["profile"] = {
+        "file": f"profiles/{pfile.name}",
+        "git_head": prof.get("git_head"),
+        "csrc_sha256_16": prof.get("csrc_sha256_16"),
+        "matches_source": prof.get("csrc_sha256_16") == csrc_hash(),
+        "kernel_us_under_pmc": entry.get("mean_us_under_pmc"),
+    }
+    return roof
 
 
 def cpu_baseline(work, budget_pairs):
@@ -257,7 +411,7 @@ def cpu_baseline(work, budget_pairs):
     }
 
 
-def run_c5(args, rank, world, device, dist):
+def run_c5(args, comm, device):
     """BASELINE configs[4]: three hap / pop / suep shaped cohorts, levels mode (compare_terms), categories
     filtered, intersection_vs_union then fuzzy_match for every cohort pair.  One step = the six grids.
     The left rows of every cohort pair are divided over the ranks (total work fixed: "strong")."""
@@ -267,6 +421,7 @@ def run_c5(args, rank, world, device, dist):
     from napkon_string_matching_amd import _lib, distributed, grid, synthetic, tables
     from napkon_string_matching_amd.compare import score_functions as sf
 
+    rank, world = comm.rank, comm.world
     lib = _lib.load()
     rows = args.rows or 500_000
     threshold = 0.7 if args.threshold is None else args.threshold  # max(cache 0.5, score 0.7), config.yml:11-12
@@ -325,9 +480,10 @@ def run_c5(args, rank, world, device, dist):
                 pending[k] = None
             b.count.zero_()
             launch(g, b)
-            lib.nsm_sort_hits(b.records.data_ptr(), b.scratch.data_ptr(), b.capacity, b.count.data_ptr(), stream)
+            _lib.check(lib.nsm_sort_hits(b.records.data_ptr(), b.scratch.data_ptr(), b.capacity, b.count.data_ptr(), stream),
+                       "nsm_sort_hits")
             if world > 1:
-                pending[k] = gather_hits(b, gathered[k], world, device, async_op=True)
+                pending[k] = comm.gather_hits(b, gathered[k], async_op=True)
             if record:
                 counts.append(int(b.count.item()))
 
@@ -336,8 +492,7 @@ def run_c5(args, rank, world, device, dist):
             if pending[k] is not None:
                 pending[k].wait()
                 pending[k] = None
-        if world > 1:
-            dist.barrier()
+        comm.barrier()
         torch.cuda.synchronize(device)
 
     for _ in range(max(1, args.warmup)):
@@ -347,17 +502,13 @@ def run_c5(args, rank, world, device, dist):
     for _ in range(args.steps):
         step()
     fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = comm.max_seconds(time.perf_counter() - t0)
     step(record=True)
     fence()
     if max(counts) > capacity:
         raise SystemExit(f"hit buffer overflow ({max(counts)} > {capacity}); raise --capacity")
 
-    # dominant kernel: indel_levels_kernel (the three fuzzy grids of a step), HIP events on the launch stream
+    # dominant kernel: the three fuzzy grids of a step, HIP events on the launch stream
     def kernel_ms(kind, reps):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         b = bufs[0]
@@ -376,7 +527,7 @@ def run_c5(args, rank, world, device, dist):
     pairs_per_step = 2 * len(pairs) * rows * rows  # both score functions over every cohort pair
     local_pairs = len(pairs) * (hi - lo) * rows    # pairs one fuzzy pass of this rank scores
     bytes_per_pair = 2 * 4 * 64                     # both items' level storage: 4 level strings of 64 B each
-    achieved = local_pairs * bytes_per_pair / (ms_indel * 1e-3) / 1e9
+    str_bytes = sum(t.nbytes() for g in grids if g[0] == "indel" for t in (g[1][1], g[1][3]))
     result = {
         "metric": "pair-comparisons/sec (whole node), N x M all-pairs",
         "value": pairs_per_step * args.steps / dt,
@@ -398,20 +549,14 @@ def run_c5(args, rank, world, device, dist):
             "pairs_per_step": pairs_per_step,
             "hits_per_grid_this_rank": counts,
             "sharding": f"left rows of every cohort pair block-sharded over {world} rank(s), right replicated, hits all-gathered",
+            "exchange": comm.exchange,
             "encode_and_h2d_seconds_once": round(t_encode, 2),
+            "fuzzy_grids_ms_per_step": ms_indel,
+            "jaccard_grids_ms_per_step": ms_jac,
         },
-        "roofline": {
-            "bound": "hbm",
-            "kernel": "indel_levels_kernel<1> (3 launches per step)",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": None,
-            "kernel_ms": ms_indel,
-            "algorithmic_bytes_per_pair": bytes_per_pair,
-            "jaccard_levels_kernel_ms": ms_jac,
-        },
+        "roofline": valu_roofline("c5", "indel_levels_park_kernel<1>", "indel_levels_park_kernel<1> (3 launches per step)",
+                                  ms_indel, len(pairs), local_pairs // len(pairs) * bytes_per_pair, str_bytes // len(pairs),
+                                  default_shape=not args.rows and args.threshold is None and world == 1),
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import compare as oc
@@ -435,69 +580,30 @@ def run_c5(args, rank, world, device, dist):
                       "(Python; fuzzy_match = pure-Python LCS, NOT rapidfuzz)",
             "seconds": round(dt_cpu, 2), "host_cpus": os.cpu_count(),
         }
-    if rank == 0:
-        print(json.dumps(result))
+    return result
 
 
-def main():
-    args = parse_args()
+def run_raw(args, comm, device, name, rows=0, right_rows=0, threshold=None, steps=None, warmup=None, extras=True):
+    """One RAW-mode / term workload under the contract: W warm-up steps, K timed steps between
+    barrier + synchronize fences, MAX over the ranks.  Returns the JSON object."""
     import torch
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the match loop has no CPU fallback")
-    local_rank = local_rank % torch.cuda.device_count()  # rehearsal: several ranks may share a GPU
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
+    from napkon_string_matching_amd import _lib, grid
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC
-        if args.dist_backend == "nccl":
-            from datetime import timedelta
-
-            try:  # RCCL; one tiny collective up front so that a broken transport shows here, not mid-run
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device,
-                                        timeout=timedelta(seconds=300))
-                probe = torch.ones(1, device=device)
-                dist.all_reduce(probe)
-                torch.cuda.synchronize(device)
-                assert int(probe.item()) == world
-            except Exception as exc:  # keep the run alive: the same exchange staged through host memory
-                print(f"[bench] RCCL unavailable ({type(exc).__name__}: {exc}); falling back to the gloo-staged exchange",
-                      file=sys.stderr)
-                try:
-                    dist.destroy_process_group()
-                except Exception:
-                    pass
-                args.dist_backend = "gloo"
-                dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-
-    from napkon_string_matching_amd import grid
-
-    if args.workload == "c4" and args.capacity == 1 << 13:
-        args.capacity = 1 << 16  # ~12k hits at 1M x 1M
-    if args.workload == "term" and args.capacity == 1 << 13:
-        args.capacity = 1 << 24  # ~2.3 % of the pairs reach the cache threshold 0.5
-    if args.workload == "c5":
-        run_c5(args, rank, world, device, dist)
-        if world > 1:
-            dist.destroy_process_group()
-        return
-    work = Workload(args.workload, rank, world, args.rows, device, args.right_rows, args.threshold)
+    rank, world = comm.rank, comm.world
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    capacity = args.capacity
+    if name == "c4" and capacity == 1 << 13:
+        capacity = 1 << 16  # ~12k hits at 1M x 1M
+    if name == "term" and capacity == 1 << 13:
+        capacity = 1 << 24  # ~2.6 % of the pairs reach the cache threshold 0.5
+    work = Workload(name, comm, rows, device, right_rows, threshold)
+    # the committed profile describes the workload's default per-GPU grid (c4 divides its rows over the ranks)
+    default_shape = not rows and not right_rows and threshold is None and (name != "c4" or world == 1)
     # two hit buffers: the all-gather of step k overlaps the grid kernel of step k+1 (RCCL runs on
     # its own stream; the buffer is only reused after its gather has completed)
-    bufs = [grid.HitBuffer(args.capacity, device) for _ in range(2)]
+    bufs = [grid.HitBuffer(capacity, device) for _ in range(2)]
     for b in bufs:
         b.scratch = torch.empty_like(b.records)
     gathered = [torch.empty((world,) + tuple(b.storage.shape), dtype=b.storage.dtype, device=device) for b in bufs]
@@ -536,43 +642,35 @@ def main():
         else:
             b.count.zero_()
             work.launch(b, stream, prune)
-            lib.nsm_sort_hits(b.records.data_ptr(), b.scratch.data_ptr(), b.capacity, b.count.data_ptr(), stream)
+            _lib.check(lib.nsm_sort_hits(b.records.data_ptr(), b.scratch.data_ptr(), b.capacity, b.count.data_ptr(), stream),
+                       "nsm_sort_hits")
         if world > 1:
-            pending[k] = gather_hits(b, gathered[k], world, device, async_op=True)
+            pending[k] = comm.gather_hits(b, gathered[k], async_op=True)
 
-    def drain():
+    def fence():
         for k in (0, 1):
             if pending[k] is not None:
                 pending[k].wait()
                 pending[k] = None
-
-    def fence():
-        drain()
-        if world > 1:
-            dist.barrier()
+        comm.barrier()
         torch.cuda.synchronize(device)
 
-    def timed(steps, prune):
+    def timed(n_steps, prune):
         fence()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(n_steps):
             step(prune)
         fence()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=device if args.dist_backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
+        return comm.max_seconds(time.perf_counter() - t0)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step(True)
-    dt = timed(args.steps, True)
+    dt = timed(steps, True)
     n_hits = int(buf.count.item())
     if n_hits > buf.capacity:
         raise SystemExit(f"hit buffer overflow ({n_hits} > {buf.capacity}); raise --capacity")
     pairs_per_step = work.n * work.m * world
-    value = pairs_per_step * args.steps / dt
+    value = pairs_per_step * steps / dt
 
     # ---- per-kernel duration of the dominant kernel, HIP events on the launch stream
     def kernel_ms(prune, reps):
@@ -587,33 +685,17 @@ def main():
         torch.cuda.synchronize(device)
         return ev0.elapsed_time(ev1) / reps
 
-    k_ms = kernel_ms(True, max(3, args.steps))
-    # exhaustive variant (prune off): fewer repetitions, it is the slow one
-    ex_steps = max(2, min(args.steps, 5))
-    step(False)
-    dt_ex = timed(ex_steps, False)
-    k_ms_ex = kernel_ms(False, ex_steps)
-
-    def roof(ms):
-        achieved = work.n * work.m * work.bytes_per_pair / (ms * 1e-3) / 1e9
-        return achieved
-
-    traffic = None
-    tfile = ROOT / "profiles" / f"traffic_{work.name}.json"  # measured by tools/refresh_profiles.sh
-    if tfile.exists():
-        try:
-            traffic = json.loads(tfile.read_text()).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-
+    k_ms = kernel_ms(True, max(3, steps))
+    alg_bytes = work.n * work.m * work.bytes_per_pair
+    compulsory = work.left.nbytes() + work.right.nbytes() + n_hits * 16
     result = {
         "metric": "pair-comparisons/sec (whole node), N x M all-pairs",
         "value": value,
         "unit": "pair-comparisons/s",
         "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": dt / steps * 1e3,
         "higher_is_better": True,
         "scaling": work.scaling,
         "vs_baseline": None,
@@ -627,52 +709,68 @@ def main():
             "pairs_per_step": pairs_per_step,
             "hits_per_rank": n_hits,
             "sharding": f"left rows block-sharded over {world} rank(s), right replicated, hits all-gathered",
-            "exchange": None if world == 1 else ("rccl all-gather" if args.dist_backend == "nccl" else "gloo, staged through host memory"),
+            "exchange": comm.exchange,
+            "rccl_ranks_seen": comm.rccl_ranks,
             "exact_prune": True,
             "encode_and_h2d_seconds_once": round(work.encode_h2d_seconds, 4),
         },
-        "roofline": {
-            "bound": "hbm",
-            "kernel": work.kernel + " (exact prune on)",
-            "achieved": roof(k_ms),
-            "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s",
-            "frac": roof(k_ms) / HBM_PEAK_GBPS,
-            "traffic": traffic,
-            "hbm_measured_GBps": None if traffic is None else traffic / (k_ms * 1e-3) / 1e9,
-            "kernel_ms": k_ms,
-            "algorithmic_bytes_per_launch": work.n * work.m * work.bytes_per_pair,
-            "compulsory_hbm_bytes_per_launch": work.left.nbytes() + work.right.nbytes() + n_hits * 16,
-        },
-        "exhaustive": {
+        "roofline": valu_roofline(work.name, work.kernel_match, work.kernel + " (exact prune on)", k_ms, 1, alg_bytes,
+                                  compulsory, default_shape=default_shape),
+    }
+    if extras:
+        # exhaustive variant (prune off): fewer repetitions, it is the slow one
+        ex_steps = max(2, min(steps, 5))
+        step(False)
+        dt_ex = timed(ex_steps, False)
+        k_ms_ex = kernel_ms(False, ex_steps)
+        ex_roof = valu_roofline(work.name, work.kernel_match_exhaustive, work.kernel, k_ms_ex, 1, alg_bytes, compulsory,
+                                default_shape=default_shape)
+        result["exhaustive"] = {
             "note": "same grid, exact prune disabled: every pair's full comparison is evaluated",
             "value": pairs_per_step * ex_steps / dt_ex,
             "ms_per_step": dt_ex / ex_steps * 1e3,
             "kernel_ms": k_ms_ex,
-            "achieved_GBps": roof(k_ms_ex),
-            "frac": roof(k_ms_ex) / HBM_PEAK_GBPS,
-        },
-    }
-    # The honest limiter of the pruned kernel is the VALU issue rate of its per-row filter, not HBM (DESIGN.md
-    # 4.0/4.1/4.3): filter instructions per (wavefront, left row) x their measured issue cycles
-    # (profiles/r01_valu_issue_rates_gfx950.txt) against the kernel's measured duration.
-    filter_cycles = 8 * 4.3 + 2.3 if work.name == "c3" else 4 * 4.3 + 2.3  # 8 v_sad_u8 + v_or | 2 v_and + 2 v_bcnt + v_and
-    wave_rows = -(-work.m // 64) * work.n
-    ideal_ms = wave_rows * filter_cycles / (256 * 4 * 2.4e9) * 1e3
-    result["limiter"] = {
-        "bound": "valu_issue",
-        "note": "filter cycles per (wavefront, left row) x all wave-rows / (1024 SIMDs x 2.4 GHz); size-class skips "
-                "make the true work smaller, survivors and loop overhead make it larger",
-        "filter_cycles_per_wave_row": filter_cycles,
-        "ideal_kernel_ms": ideal_ms,
-        "frac": ideal_ms / k_ms,
-    }
+            "valu_issue_frac": ex_roof.get("frac"),
+            "lds_busy_frac": ex_roof.get("lds_busy_frac"),
+        }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(work, {"c3": 80_000, "term": 360_000}.get(work.name, 20_000_000))
+    return result
+
+
+def main():
+    args = parse_args()
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the match loop has no CPU fallback")
+    local_rank = local_rank % torch.cuda.device_count()  # rehearsal: several ranks may share a GPU
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    comm = Comm(args, rank, world, device)
+    assert comm.world == args.gpus
+
+    if args.workload == "c5":
+        result = run_c5(args, comm, device)
+    else:
+        result = run_raw(args, comm, device, args.workload, args.rows, args.right_rows, args.threshold)
+        if world > 1 and args.workload == "c2" and not args.no_c4 and not args.rows:
+            # the SCALE record also covers BASELINE configs[3]: 1M x 1M, threshold 0.8, the left rows divided
+            # over the ranks ("strong"); a short run, attached beside the headline
+            c4 = run_raw(args, comm, device, "c4", steps=max(2, min(args.steps, 5)), warmup=1, extras=False)
+            result["c4"] = {k: c4[k] for k in ("value", "unit", "ms_per_step", "steps", "scaling")}
+            result["c4"].update({"workload": c4["config"]["workload"], "hits_per_rank": c4["config"]["hits_per_rank"],
+                                 "exchange": c4["config"]["exchange"], "kernel_ms": c4["roofline"]["kernel_ms"]})
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
-        dist.destroy_process_group()
+    comm.close()
 
 
 if __name__ == "__main__":

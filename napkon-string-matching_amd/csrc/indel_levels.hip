@@ -391,6 +391,15 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
       return NSM_E_UNSUPPORTED;
     }
     dim3 pgrid((n_tiles + pw - 1) / pw, grid.y);
+    if (left->seg) {
+      // partitioned: y = slices of every category's row range (all blocks have work); ~256 rows per slice when
+      // the rows spread over ~32 categories, enough blocks to fill the chip when they do not
+      long long slices = (left->n + 8191) / 8192;
+      if (slices < 1) slices = 1;
+      if (slices > 1024) slices = 1024;
+      while (slices < 64 && static_cast<long long>(pgrid.x) * slices < 4096) slices *= 2;
+      pgrid.y = static_cast<unsigned>(slices);
+    }
 #define NSM_LAUNCH_PARK(KK)                                                                                       \
   hipLaunchKernelGGL((indel_levels_park_kernel<KK>), pgrid, dim3(pw * kWave), park_lds,                          \
                      static_cast<hipStream_t>(stream), left->first, left->nlev, left->orig, left->cat,           \

@@ -53,6 +53,10 @@ constexpr uint16_t kDeadNeed = 0xffff;
 #endif
 // 4 waves per SIMD (128 VGPRs): left alone hipcc settles at 169 VGPRs = 2 waves, and the kernel's latency-bound
 // phases then run 1.4x slower (3 x 100k^2 levels bench: 38.4 vs 26.7 ms); the spills this forces sit in the dense pass
+// step-1 pre-filter: 1 = histogram bound of the step-1 level pair (4-8 more v_sad_u8 per pair), 0 = lengths only
+#ifndef NSM_PARK_H1
+#define NSM_PARK_H1 0
+#endif
 #ifndef NSM_PARK_OCC
 #define NSM_PARK_OCC __attribute__((amdgpu_waves_per_eu(4, 4)))
 #endif
@@ -174,8 +178,12 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
   const int jc = valid ? j : p.n_right - 1;
   const bool partitioned = rseg != nullptr;
   const int myseg = partitioned ? rseg[jc] : 0;
-  const int i0 = blockIdx.y * p.rows_per_chunk;
-  const int i1 = min(p.n_left, i0 + p.rows_per_chunk);
+  // Left rows of this block.  Without a partition: chunk blockIdx.y of rows_per_chunk rows.  With one: slice
+  // blockIdx.y of gridDim.y of EACH of the tiles' categories' row ranges -- every block has work (a grid of
+  // (tile block, row chunk) pairs is 97 % blocks that find no row of their categories and leave: 7 % of the
+  // kernel's time at configs[4]'s shape).
+  const int i0 = partitioned ? 0 : blockIdx.y * p.rows_per_chunk;
+  const int i1 = partitioned ? p.n_left : min(p.n_left, i0 + p.rows_per_chunk);
   const bool use_hist = p.use_hist != 0;
 
   if (threadIdx.x == 0) s_cats = 0ull;
@@ -201,16 +209,6 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
   }
   __syncthreads();
   const unsigned long long cats_block = s_cats;  // block-uniform from here on
-  if (partitioned) {  // most (tiles, chunk) combinations hold no row of the tiles' categories: leave early
-    bool work = false;
-    for (unsigned long long cats = cats_block; cats;) {
-      const int c = __builtin_ctzll(cats);
-      cats &= cats - 1;
-      work = work || (max(i0, lsegstart[c]) < min(i1, lsegstart[c + 1]));
-    }
-    if (!work) return;  // the whole block
-  }
-
   // ---- the lane's right item
   const int lr = rnlev[jc];
   const int rrow0 = rfirst[jc];
@@ -317,12 +315,17 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
   // wave's own tile; leftovers may still be parked once they are few).
   auto dense_steps = [&](int ib, int nrows, bool active, int r, int jr, int s0, double score, bool packed,
                          int reg) __attribute__((always_inline)) {
+    // (Requesting everything a step needs at its top -- text, next step's histograms -- was tried: the 32 more
+    // live registers spilled and the dense pass went from 5.5 to 22 ms per 3 x 100k^2 grids.)
     const int i = ib + r;
     const int ll = lnlev[i], lf = lfirst[i];
     const int lrj = rnlev[jr], rr0 = rfirst[jr];
-    if (packed && active) {  // the score of step 1 is 2^-1 * ratio (idle lanes carry no LCS: never index the table with one)
+    // lane q < nrows also looks after batch row q's mask table
+    const int q_lf = lane < nrows ? lfirst[ib + lane] : 0;
+    const int q_ll = lane < nrows ? lnlev[ib + lane] : 1;
+    if (packed && active) {  // the score of step 1 is 2^-1 * ratio (idle lanes carry no LCS)
       const int lcs1 = static_cast<int>(__double_as_longlong(score));
-      score = ratio_of(llen[lf + max(0, min(1, ll - 1))], rlen[rr0 + max(0, min(1, lrj - 1))], lcs1) * 0.5;
+      score = indel_score_dev(llen[lf + max(0, min(1, ll - 1))], rlen[rr0 + max(0, min(1, lrj - 1))], lcs1) * 0.5;
     }
     const int S = max(ll, lrj);
     const int s_lo = 64 - wave_max_i32(active ? 64 - s0 : 0);  // smallest next step (steps <= 64)
@@ -340,36 +343,47 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
       if (__any(fresh)) {
         const int lrow = lf + a, rrow = rr0 + b;
         const int la = llen[lrow], lbj = rlen[rrow];
+        const int my_lrow = q_lf + max(0, min(s, q_ll - 1));
+        const int my_la = llen[my_lrow];
         int lcs = 0;
         for (int g0 = 0; g0 < nrows; g0 += p.fin_rows) {
           const bool mine = fresh && r >= g0 && r < g0 + p.fin_rows;
           const uint32_t rows_here = wave_reduce_u32(mine ? (1u << r) : 0u, [](uint32_t x, uint32_t y) { return x | y; });
           if (!rows_here) continue;
-          // the group's mask tables, one per left row present: request every row's code units first, then
-          // zero, then set the bits (one memory latency for the group instead of one per row)
-          int la_max = 0;
+          const uint8_t* tptr = rcodes + static_cast<size_t>(mine ? rrow : rr0) * kRow;
+          // the group's mask tables, one per left row present: every row's code units are requested before
+          // the first is used, then the tables are zeroed and the bits set
+          unsigned cu[kBatch][K];
+#pragma unroll
+          for (int q = 0; q < kBatch; ++q) {
+            const int rr = g0 + q;
+            if (q < p.fin_rows && ((rows_here >> rr) & 1u)) {
+              const int lrow_u = __builtin_amdgcn_readlane(my_lrow, rr);
+#pragma unroll
+              for (int k = 0; k < K; ++k) cu[q][k] = lcodes[static_cast<size_t>(lrow_u) * kRow + lane + kWave * k];
+            }
+          }
           for (int c = lane; c < p.fin_rows * tbl_entries; c += kWave) pm[c] = 0ull;
+          if constexpr (K > 1) wide_store_text<K>(wtext, tptr, lane);
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
-          for (uint32_t rows = rows_here; rows;) {
-            const int rr = __builtin_ctz(rows);
-            rows &= rows - 1;
-            const int ii = ib + rr;
-            const int lrow_u = lfirst[ii] + max(0, min(s, lnlev[ii] - 1));
-            const int la_u = llen[lrow_u];
-            la_max = max(la_max, la_u);
-            unsigned long long* tb = pm + static_cast<size_t>(rr - g0) * tbl_entries;
+          int la_max = 0;
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-              const int pos = lane + kWave * k;
-              if (pos < la_u) atomicOr(&tb[lcodes[static_cast<size_t>(lrow_u) * kRow + pos] * K + k], 1ull << lane);
+          for (int q = 0; q < kBatch; ++q) {
+            const int rr = g0 + q;
+            if (q < p.fin_rows && ((rows_here >> rr) & 1u)) {
+              const int la_u = __builtin_amdgcn_readlane(my_la, rr);
+              la_max = max(la_max, la_u);
+              unsigned long long* tb = pm + static_cast<size_t>(q) * tbl_entries;
+#pragma unroll
+              for (int k = 0; k < K; ++k)
+                if (lane + kWave * k < la_u) atomicOr(&tb[cu[q][k] * K + k], 1ull << lane);
             }
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
           __builtin_amdgcn_wave_barrier();
           const unsigned long long* tbl = pm + static_cast<size_t>(mine ? r - g0 : 0) * tbl_entries;
           const int nchars = wave_max_i32(mine ? lbj : 0);
-          const uint8_t* tptr = rcodes + static_cast<size_t>(mine ? rrow : rr0) * kRow;
           int got;
           if constexpr (K == 1) {
             uint32_t text[16];
@@ -392,13 +406,12 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
             }
             got = 64 - __popcll(v);
           } else {
-            wide_store_text<K>(wtext, tptr, lane);
             got = wide_lcs<K>(tbl, wtext, nchars, lane, la_max);
           }
           if (mine) lcs = got;
         }
         if (fresh) {
-          ratio = ratio_of(la, lbj, lcs);
+          ratio = indel_score_dev(la, lbj, lcs);  // arithmetic, not the table: no gather in the chain
           prev_a = a;
           prev_b = b;
         }
@@ -409,8 +422,7 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
         // float arithmetic of the bound and the rounding of the double sum)
         float rest = 0.0f;
         if (s < S) {
-          const int t = s + 1;
-          const int lrow_n = lf + max(0, min(t, ll - 1)), rrow_n = rr0 + max(0, min(t, lrj - 1));
+          const int lrow_n = lf + max(0, min(s + 1, ll - 1)), rrow_n = rr0 + max(0, min(s + 1, lrj - 1));
           rest = rest_bound(s, S, step_ub(lrow_n, rrow_n, llen[lrow_n], rlen[rrow_n]));
         }
         alive = score + static_cast<double>(rest) + 1e-6 >= p.threshold;
@@ -441,6 +453,9 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
   // ---- this wave's tile against the batch rows [ib, ib + nrows); okbits bit r = the lane passes the
   // category predicate for row ib + r; survivors go to park region `reg`
   auto scan_batch = [&](int ib, int nrows, uint32_t okbits, uint32_t rows_ok, int reg) __attribute__((always_inline)) {
+#ifdef NSM_X_EMPTY
+    return;
+#endif
     // ---- stage: heads of the batch's rows (lane = (row, step 1..3))
     if (lane < nrows * 3) {
       const int r = lane / 3, t = lane - 3 * r;
@@ -477,13 +492,14 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
         la[t] = static_cast<int>(rec[t * kHeadDwords + NB]);
-        if (use_hist) {
+        l1[t] = 0u;
+        if (use_hist && (t > 0 || NSM_PARK_H1)) {
           uint32_t hl[NB];
 #pragma unroll
           for (int q = 0; q < NB; ++q) hl[q] = rec[t * kHeadDwords + q];
           l1[t] = hist_l1<NB>(hl, hb[t]);
-        } else {
-          l1[t] = t == 0 ? static_cast<uint32_t>(abs(la[0] - lb_t[0])) : 0u;
+        } else if (t == 0) {
+          l1[0] = static_cast<uint32_t>(abs(la[0] - lb_t[0]));  // LCS <= min(la, lb)
         }
       }
       // alive after step 1  <=>  lcs / n1 + R >= thr,  R = (w2 + w3 + c) - w2 l2 / n2 - w3 l3 / n3;
@@ -500,6 +516,9 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
       live |= __any(can) ? (1u << r) : 0u;
     }
     if (!live) return;
+#ifdef NSM_X_HONLY
+    return;
+#endif
 
     // ---- step 1, wave-wide
     stage_strings(ib, live, 1);
@@ -530,16 +549,94 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
     }
     const int nchars = wave_max_i32(valid ? lb : 0);
     uint32_t over = 0;  // rows whose survivors were too many to park: their remaining steps follow below
+    // what follows a row's step-1 LCS: the survivors are parked, or the row is marked for the dense steps below
+    auto after_lcs = [&](int r, int la, int lcs) __attribute__((always_inline)) {
+      const int ll = wave_first(static_cast<int>(head[r * 3 * kHeadDwords + NB + 2]));
+      const int S = max(ll, lr);
+      const int nd = need[r * kWave + lane];
+      const bool alive = nd != kDeadNeed && lcs >= nd;  // can still reach the threshold
+      if (!__any(alive)) return;
+      const bool more = alive && S > 1;
+      if (__any(alive && !more)) {  // single-step pairs (both items have one level): final here
+        const double score = ratio_of(la, lb, lcs) * 0.5;
+        const bool hit = alive && !more && score >= p.threshold;
+        if (__any(hit)) {
+          if (hit) emit_hit(hits, p.cap, count, score, lorig[ib + r], jorig);
+        }
+      }
+      const unsigned long long who = __ballot(more);
+      if (who == 0ull) return;
+      const int n = __popcll(who);
+      int have = -1;
+      if (n <= p.park_max) have = reserve(reg, n);
+      if (have >= 0) {
+        // parked with the LCS itself (bit 16 of meta): the dense pass turns it into the score -- the ratio
+        // table is a gather from L2 whose latency would be paid per row here
+        if (more) {
+          const int slot = (reg % kSub) * p.park_slots + have +
+                           __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(who >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(who), 0u));
+          park_score[slot] = __longlong_as_double(static_cast<long long>(lcs));
+          park_j[slot] = jc;
+          park_meta[slot] = r | (2 << 8) | 0x10000;
+        }
+      } else {  // dense enough (or the park is full): the row's remaining steps are scored by this wave itself
+        need[r * kWave + lane] = more ? static_cast<uint16_t>(lcs) : kDeadNeed;
+        over |= 1u << r;
+      }
+    };
     for (uint32_t rows = live; rows;) {
       const int r = __builtin_ctz(rows);
       rows &= rows - 1;
-      const uint32_t* rec = head + r * 3 * kHeadDwords;
-      const int ll = wave_first(static_cast<int>(rec[NB + 2]));
-      const int S = max(ll, lr);
-      const int nd = need[r * kWave + lane];
-      const int la = wave_first(static_cast<int>(rec[NB]));
+      const int la = wave_first(static_cast<int>(head[r * 3 * kHeadDwords + NB]));
+      if constexpr (K == 1) {
+        // Two left rows per pass when both fit 32-bit words: row A's masks in the low, row B's in the high half
+        // of ONE table entry, so a code unit of the text costs one address op and one ds_read_b64 for both
+        // rows, and the two recurrences are independent chains the SIMD can interleave.  (Per row: 4.5 VALU ops
+        // per code unit instead of 5, half the LDS reads, half the table builds and loop overhead.)
+        const int r2 = rows ? __builtin_ctz(rows) : -1;
+        const int la2 = r2 >= 0 ? wave_first(static_cast<int>(head[r2 * 3 * kHeadDwords + NB])) : 64;
+        if (la <= 32 && la2 <= 32) {
+          rows &= rows - 1;
+          for (int c = lane; c < tbl_entries; c += kWave) pm[c] = 0ull;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          uint32_t* pm32 = reinterpret_cast<uint32_t*>(pm);
+          if (lane < la) atomicOr(&pm32[2 * lstr[r * kRow + lane]], 1u << lane);
+          if (lane < la2) atomicOr(&pm32[2 * lstr[r2 * kRow + lane] + 1], 1u << lane);
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          asm volatile("" : "+v"(lowmask), "+v"(sh16));
+          uint32_t va = ~0u, vb = ~0u;
+#pragma unroll
+          for (int g = 0; g < 8; ++g) {
+            if (g * 8 < nchars) {
+              unsigned long long m[8];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                m[2 * q] = lev_lds_load<unsigned long long>(taddr[4 * g + q] & lowmask);
+                m[2 * q + 1] = lev_lds_load<unsigned long long>(taddr[4 * g + q] >> sh16);
+              }
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                va = lcs_step32(va, static_cast<uint32_t>(m[q]));
+                vb = lcs_step32(vb, static_cast<uint32_t>(m[q] >> 32));
+              }
+            }
+          }
+          after_lcs(r, la, 32 - __popc(va));
+          after_lcs(r2, la2, 32 - __popc(vb));
+          continue;
+        }
+      }
+#ifndef NSM_X_NOPM
       build_pm_staged(r, la);
+#endif
       int lcs;
+#ifdef NSM_X_NOLCS
+      lcs = 0;
+      if (false)
+#endif
       if constexpr (K == 1) {
         // opaque per row: otherwise the 64 unpacked addresses are hoisted out of the row loop into 64
         // more VGPRs
@@ -582,36 +679,7 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
       } else {
         lcs = wide_lcs<K>(pm, wtext, nchars, lane, la);
       }
-      const bool alive = nd != kDeadNeed && lcs >= nd;  // can still reach the threshold
-      if (!__any(alive)) continue;
-      const bool more = alive && S > 1;
-      if (__any(alive && !more)) {  // single-step pairs (both items have one level): final here
-        const double score = ratio_of(la, lb, lcs) * 0.5;
-        const bool hit = alive && !more && score >= p.threshold;
-        if (__any(hit)) {
-          if (hit) emit_hit(hits, p.cap, count, score, lorig[ib + r], jorig);
-        }
-      }
-      const unsigned long long who = __ballot(more);
-      if (who == 0ull) continue;
-      const int n = __popcll(who);
-      int have = -1;
-      if (n <= p.park_max) have = reserve(reg, n);
-      if (have >= 0) {
-        // parked with the LCS itself (bit 16 of meta): the dense pass turns it into the score -- the ratio
-        // table is a gather from L2 whose latency would be paid per row here
-        if (more) {
-          const int slot = (reg % kSub) * p.park_slots + have +
-                           __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(who >> 32),
-                                                     __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(who), 0u));
-          park_score[slot] = __longlong_as_double(static_cast<long long>(lcs));
-          park_j[slot] = jc;
-          park_meta[slot] = r | (2 << 8) | 0x10000;
-        }
-      } else {  // dense enough (or the park is full): the row's remaining steps are scored by this wave itself
-        need[r * kWave + lane] = more ? static_cast<uint16_t>(lcs) : kDeadNeed;
-        over |= 1u << r;
-      }
+      after_lcs(r, la, lcs);
     }
     if (over) {
       text_row = -1;  // the text image's registers are free for the dense steps
@@ -628,8 +696,13 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
   for (unsigned long long cats = cats_block; cats;) {  // the same sequence in every wave of the block
     const int c = __builtin_ctzll(cats);
     cats &= cats - 1;
-    const int a = partitioned ? max(i0, lsegstart[c]) : i0;
-    const int b = partitioned ? min(i1, lsegstart[c + 1]) : i1;
+    int a = i0, b = i1;
+    if (partitioned) {  // slice blockIdx.y of the category's rows, cut at batch boundaries
+      const int lo = lsegstart[c], len = lsegstart[c + 1] - lo;
+      const int per = (((len + static_cast<int>(gridDim.y) - 1) / static_cast<int>(gridDim.y)) + kBatch - 1) / kBatch * kBatch;
+      a = lo + min(len, static_cast<int>(blockIdx.y) * per);
+      b = lo + min(len, (static_cast<int>(blockIdx.y) + 1) * per);
+    }
     const unsigned long long lower = (1ull << c) - 1ull;
     for (int sb = a; sb < b; sb += kBatch * kSub) {
       for (int g = 0; g < kSub; ++g) {
@@ -657,6 +730,7 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
         const int ib = sb + g * kBatch;
         if (ib >= b) break;
         const int n_p = min(s_cnt[pb * kSub + g], s_valid[pb * kSub + g]);
+#ifndef NSM_NO_FINISH
         for (int base = 0; base < n_p; base += kWave) {
           const bool active = base + lane < n_p;
           const int slot = g * p.park_slots + (active ? base + lane : base);
@@ -664,6 +738,7 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
           dense_steps(ib, min(kBatch, b - ib), active, meta & 0xff, park_j[slot], (meta >> 8) & 0xff, park_score[slot],
                       (meta & 0x10000) != 0, -1);
         }
+#endif
       }
       __syncthreads();  // the park has been read
       pb ^= 1;

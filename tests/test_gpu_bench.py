@@ -23,20 +23,63 @@ def _line(cmd):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("workload", ["c2", "c3", "c4", "c5"])
+def _check_roofline(roof, need_frac):
+    assert roof["bound"] == "valu_issue" and roof["peak"] == pytest.approx(1228.8) and "traffic" in roof
+    assert roof["kernel_ms"] > 0 and roof["algorithmic_bytes_per_launch"] > 0
+    if need_frac:
+        assert roof["profile"]["file"].startswith("profiles/pmc_")
+    if roof["frac"] is not None:  # a fraction of a bound: never above 1
+        assert 0.0 < roof["frac"] <= 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+        assert 0.0 < roof["frac_pmc"] <= 1.0
+        assert roof["hbm_frac"] is None or 0.0 <= roof["hbm_frac"] <= 1.0
+    else:
+        assert not need_frac, roof
+
+
+@pytest.mark.parametrize("workload", ["c2", "c3", "c4", "c5", "term"])
 def test_bench_line(workload):
-    rows = {"c2": "8000", "c3": "8000", "c4": "60000", "c5": "6000"}[workload]
+    rows = {"c2": "8000", "c3": "8000", "c4": "60000", "c5": "6000", "term": "3000"}[workload]
     d = _line([sys.executable, "bench.py", "--workload", workload, "--rows", rows, "--steps", "2", "--warmup", "1"])
     assert all(k in d for k in CONTRACT), sorted(d)
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["higher_is_better"] is True
     assert d["unit"] == "pair-comparisons/s" and d["data"] == "synthetic" and d["vs_baseline"] is None
-    assert "workload" in d["config"] and "model" not in d["config"]
-    roof = d["roofline"]
-    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
-    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and "traffic" in roof
+    assert "workload" in d["config"] and "model" not in d["config"] and "limiter" not in d
+    _check_roofline(d["roofline"], need_frac=False)  # reduced grid: the committed profile does not apply
     cpu = d["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["value"] > 0 and cpu["sample"]
-    assert d["scaling"] == ("weak" if workload in ("c2", "c3") else "strong")
+    assert d["scaling"] == ("weak" if workload in ("c2", "c3", "term") else "strong")
+
+
+def test_bench_default_roofline_is_a_fraction():
+    """The default invocation's roofline is a fraction of a bound the kernel can approach: in (0, 1], backed by
+    the committed counter profile (round-1 verdict: 91.6 of HBM peak is not a roofline)."""
+    d = _line([sys.executable, "bench.py", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"])
+    _check_roofline(d["roofline"], need_frac=True)
+    assert d["exhaustive"]["valu_issue_frac"] is None or 0.0 < d["exhaustive"]["valu_issue_frac"] <= 1.0
+
+
+def test_bench_rccl_failure_is_loud():
+    """Two ranks on ONE GPU cannot form an RCCL communicator: bench.py must agree on that across the ranks and
+    exit non-zero (round-1 advice: a silent, rank-local gloo fallback), and run staged when --allow-gloo is given."""
+    def launch(extra):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        return subprocess.run(
+            [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+             "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", "4000", *extra],
+            cwd=ROOT, capture_output=True, text=True, timeout=900)
+
+    out = launch([])
+    if out.returncode == 0:  # a box where two ranks may share a device: then the exchange must really be RCCL
+        line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+        assert line["config"]["exchange"] == "rccl all-gather"
+        return
+    assert "RCCL could not be brought up on every rank" in out.stderr
+    out = launch(["--allow-gloo"])
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["config"]["exchange"].startswith("gloo") and line["n_gpus"] == 2
 
 
 def test_bench_two_ranks_gloo():

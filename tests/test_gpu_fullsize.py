@@ -173,6 +173,58 @@ def test_c5_full_size_cohort_pair(dev):
         assert s == ocmp.compare_terms(a, b, osf.intersection_vs_union) and cats_ok(i, j)
 
 
+def test_c5_full_size_fuzzy_pair(dev):
+    """configs[4], the fuzzy_match leg at full size: one 500k x 500k cohort pair, 4 levels, 32 categories,
+    filter_categories, compare_terms x fuzzy_match through nsm_indel_levels_grid at the config's score
+    threshold 0.7 (reference: types/comparable_data.py:223-232, :248-265).  Size-independent properties:
+    planted copies found with the maximal score 1 - 2^-4; the hits of a lower device threshold filtered to
+    0.7 are the 0.7 run (the cache_threshold / score_threshold relation of compare(), :123-126 -- 0.65 here:
+    at the config's 0.5 half of all same-category pairs of this corpus are hits, 10^10 records); sampled hits
+    re-scored by the oracle's compare_terms; a 50k corner equals the un-partitioned grid."""
+    from napkon_string_matching_amd import _lib, grid, synthetic, tables
+    from napkon_string_matching_amd.compare import score_functions as sf
+    from oracle import compare as ocmp
+    from oracle import score_functions as osf
+
+    n = 500_000
+    hap = synthetic.c5_cohort(n, 21)
+    pop = synthetic.c5_cohort(n, 22, plant_from=hap)
+    mode = _lib.CAT_INTERSECT_OR_BOTH_EMPTY
+    lv = lambda c, rows=slice(None): [[sf.fuzzy_operand(x) for x in it] for it in synthetic.c5_level_token_lists(c, rows)]
+    la, lb = lv(hap), lv(pop)
+    li, ls, ri, rs = tables.encode_level_strings(la, lb, dev, hap["cat"], pop["cat"], mode)
+    assert li.seg is not None and ls.stride == 64
+    hits = grid.indel_levels_grid(li, ls, ri, rs, 0.7, category_mode=mode, capacity=1 << 16).as_tuples()
+    assert len(hits) >= 2000 and all(s >= 0.7 for s, _, _ in hits)
+    cats_ok = lambda i, j: bool(hap["cat"][i] & pop["cat"][j]) or (hap["cat"][i] == 0 and pop["cat"][j] == 0)
+    # (i) planted copies: identical items score 1 - 2^-4 = 0.9375 exactly
+    tok_index = {tuple(r): k for k, r in enumerate(map(tuple, hap["tok"]))}
+    planted = [(tok_index[tuple(r)], j) for j, r in enumerate(map(tuple, pop["tok"])) if tuple(r) in tok_index]
+    same = {(i, j) for s, i, j in hits if s == 0.9375}
+    assert len(planted) >= 2000 and all(pq in same for pq in planted if cats_ok(*pq))
+    # (ii) lower device threshold, filtered on the host
+    low = grid.indel_levels_grid(li, ls, ri, rs, 0.65, category_mode=mode, capacity=1 << 22).as_tuples()
+    assert len(low) > len(hits) and [h for h in low if h[0] >= 0.7] == hits
+    # (iii) sampled hits (both runs) against the oracle's compare_terms x fuzzy_match
+    sample = hits[:: max(1, len(hits) // 150)] + low[:: max(1, len(low) // 100)]
+    assert len(sample) >= 200
+    for s, i, j in sample:
+        a = synthetic.c5_level_token_lists(hap, slice(i, i + 1))[0]
+        b = synthetic.c5_level_token_lists(pop, slice(j, j + 1))[0]
+        want = ocmp.compare_terms(a, b, osf.fuzzy_match)
+        assert abs(s - want) <= 1e-6 and s == want and cats_ok(i, j)
+    # (iv) a 50k x 50k corner: partitioned == per-lane predicate == wave-wide kernel
+    m = 50_000
+    res = []
+    for part in (True, False):
+        ci, cs, di, ds = tables.encode_level_strings(la[:m], lb[:m], dev, hap["cat"][:m], pop["cat"][:m], mode, partition=part)
+        res.append(grid.indel_levels_grid(ci, cs, di, ds, 0.7, category_mode=mode).as_tuples())
+        if part:
+            res.append(grid.indel_levels_grid(ci, cs, di, ds, 0.7, category_mode=mode, wave_wide=True).as_tuples())
+    assert res[0] == res[1] == res[2] and len(res[0]) > 10
+    assert res[0] == [h for h in hits if h[1] < m and h[2] < m]
+
+
 def test_fuzzy_levels_cooperative_equals_wave_wide(dev):
     """The block-cooperative late steps of the one-word fuzzy levels kernel against the wave-wide kernel it
     replaces (NSM_FLAG_WAVE_WIDE), 25k x 25k C5-shaped items, three thresholds, with and without partition."""
