@@ -122,19 +122,19 @@ __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
   const int jorig = rorig[jc];
   const uint64_t catr = (p.cat_mode != NSM_CAT_NONE) ? rcat[jc] : 0ull;
   const int lr_max = wave_max_i32(valid ? lr : 0);
-  unsigned long long* pm = s_pm + wave * p.pm_stride * K;
-  uint32_t* wtext = reinterpret_cast<uint32_t*>(s_pm + waves * p.pm_stride * K) + wave * 16 * K * kWave;
+  unsigned long long* pm = s_pm + wave * p.pm_stride * kPmWords<K>;
+  uint32_t* wtext = reinterpret_cast<uint32_t*>(s_pm + waves * p.pm_stride * kPmWords<K>) + wave * 16 * K * kWave;
 
   // K = 1: the lane's text as LDS addresses of its symbols' match masks (wave's PM base + 8 * code),
   // two 16-bit fields per VGPR, so one full-rate v_and / v_lshrrev per symbol yields the address; built
   // once per step and used for every row of the batch
   uint32_t taddr[32];
-  const uint32_t pm_base = static_cast<uint32_t>(wave * p.pm_stride * K * 8);  // s_pm starts at LDS offset 0
+  const uint32_t pm_base = static_cast<uint32_t>(wave * p.pm_stride * kPmWords<K> * 8);  // s_pm starts at LDS offset 0
   uint32_t lowmask = 0xffffu, sh16 = 16u;  // kept in VGPRs: e32 ops with VGPR operands issue at full rate
   int text_row = -1;
   int lb = 0;
   // running scores of the batch's rows: [row][lane] doubles behind the masks (and the text image)
-  double* sc = reinterpret_cast<double*>(reinterpret_cast<uint32_t*>(s_pm + waves * p.pm_stride * K) +
+  double* sc = reinterpret_cast<double*>(reinterpret_cast<uint32_t*>(s_pm + waves * p.pm_stride * kPmWords<K>) +
                                          (K > 1 ? waves * 16 * K * kWave : 0)) +
                wave * kBatch * kWave;
 
@@ -252,9 +252,7 @@ __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
     for (int r = 0; r < nrows; ++r) {
       const double score = sc[r * kWave + lane];
       const bool hit = ((okbits >> r) & 1u) && score >= p.threshold;
-      if (__any(hit)) {
-        if (hit) emit_hit(hits, p.cap, count, score, lorig[ib + r], jorig);
-      }
+      emit_hits_wave(hits, p.cap, count, hit, score, lorig[ib + r], jorig);
     }
   };
 
@@ -333,7 +331,7 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
   }
   IndelLevParams p;
   p.n_left = left->n; p.n_right = right->n; p.cap = capacity;
-  p.pm_stride = ((left_strings->alphabet + 1) + 63) / 64 * 64;
+  p.pm_stride = ((left_strings->alphabet + 1) + 7) / 8 * 8;  // entries per mask table (the pad symbol included)
   p.cat_mode = category_mode;
   p.threshold = threshold;
   const int n_tiles = (right->n + kWave - 1) / kWave;
@@ -352,7 +350,8 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
     grid.y = (left->n + p.rows_per_chunk - 1) / p.rows_per_chunk;
   }
   const int K = stride / 64;
-  const size_t lds_wave = p.pm_stride * K * 8 + (K > 1 ? 16 * K * kWave * 4 : 0) + lev_batch(K) * kWave * 8;
+  const int pm_words = K == 1 ? 1 : K + 1;  // kPmWords<K>
+  const size_t lds_wave = p.pm_stride * pm_words * 8 + (K > 1 ? 16 * K * kWave * 4 : 0) + lev_batch(K) * kWave * 8;
   int waves = 4;
   while (waves > 1 && waves * lds_wave > 60 * 1024) waves >>= 1;  // keeps the block under 64 KiB of LDS
   dim3 grid2((n_tiles + waves - 1) / waves, grid.y);
@@ -374,7 +373,7 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
     q.park_slots = 128;
     q.park_max = 24;
     q.rows_per_chunk = p.rows_per_chunk;
-    const size_t tbl_bytes = static_cast<size_t>(q.pm_stride) * K * 8;
+    const size_t tbl_bytes = static_cast<size_t>(q.pm_stride) * pm_words * 8;
     const size_t fixed_wave = (K > 1 ? 16 * K * kWave * 4 : 0) + batch * kWave * 2 +
                               batch * 3 * kHeadDwords * 4 + batch * kWave * K;
     const size_t park_bytes = static_cast<size_t>(q.park_slots) * kSub * 16 + 66 * 16 + 8 + 4 * kSub * 4;

@@ -52,13 +52,14 @@ constexpr uint16_t kDeadNeed = 0xffff;
 #define NSM_X_GROUPS 8
 #endif
 // 4 waves per SIMD (128 VGPRs): left alone hipcc settles at 169 VGPRs = 2 waves, and the kernel's latency-bound
-// phases then run 1.4x slower (3 x 100k^2 levels bench: 38.4 vs 26.7 ms); the spills this forces sit in the dense pass
+// phases then run 1.4x slower (3 x 100k^2 levels bench: 38.4 vs 26.7 ms); the spills this forces sit in the dense pass.
+// Multi-word strings are LDS-limited to <= 2 waves by their text images: no register cap there.
 // step-1 pre-filter: 1 = histogram bound of the step-1 level pair (4-8 more v_sad_u8 per pair), 0 = lengths only
 #ifndef NSM_PARK_H1
 #define NSM_PARK_H1 0
 #endif
 #ifndef NSM_PARK_OCC
-#define NSM_PARK_OCC __attribute__((amdgpu_waves_per_eu(4, 4)))
+#define NSM_PARK_OCC __attribute__((amdgpu_waves_per_eu(K == 1 ? 4 : 1, K == 1 ? 4 : 8)))
 #endif
 constexpr int kHeadDwords = 12;  // histogram (4 folded / 8 dwords) | la | row | levels | first row
 
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
     const uint8_t* __restrict__ rhist, nsm_hit* __restrict__ hits, unsigned long long* __restrict__ count,
     const ParkParams p) {
   // LDS (dynamic, starts at offset 0 -- the one-word text images hold raw LDS addresses):
-  //   per wave: [fin_rows][pm_stride * K] u64 mask tables (the scan uses table 0)
+  //   per wave: [fin_rows][pm_stride * kPmWords<K>] u64 mask tables (the scan uses table 0)
   //             (K > 1) [16 K][64] u32 text image | [batch][64] u16 need (then the step-1 LCS)
   //             | [batch][3][12] u32 heads | [batch][64 K] u8 the step's left level strings
   //   per block: kSub park regions of park_slots: score f64 | right item row i32 | batch row + next step << 8 i32
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
 
-  const int tbl_entries = p.pm_stride * K;
+  const int tbl_entries = p.pm_stride * kPmWords<K>;
   const size_t wave_bytes = static_cast<size_t>(p.fin_rows) * tbl_entries * 8 + (K > 1 ? 16 * K * kWave * 4 : 0) +
                             kBatch * kWave * 2 + kBatch * 3 * kHeadDwords * 4 + kBatch * kRow;
   unsigned char* wbase = reinterpret_cast<unsigned char*>(s_mem) + wave * wave_bytes;
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
       const int pos = lane + kWave * k;
       if (pos < la) {
         const unsigned c = lstr[r * kRow + pos];
-        atomicOr(&pm[c * K + k], 1ull << lane);
+        atomicOr(&pm[c * kPmWords<K> + k], 1ull << lane);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
               unsigned long long* tb = pm + static_cast<size_t>(q) * tbl_entries;
 #pragma unroll
               for (int k = 0; k < K; ++k)
-                if (lane + kWave * k < la_u) atomicOr(&tb[cu[q][k] * K + k], 1ull << lane);
+                if (lane + kWave * k < la_u) atomicOr(&tb[cu[q][k] * kPmWords<K> + k], 1ull << lane);
             }
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
         }
       }
     }
-    if (active && alive && score >= p.threshold) emit_hit(hits, p.cap, count, score, lorig[i], rorig[jr]);
+    emit_hits_wave(hits, p.cap, count, active && alive && score >= p.threshold, score, lorig[i], rorig[jr]);
   };
 
   // ---- this wave's tile against the batch rows [ib, ib + nrows); okbits bit r = the lane passes the
@@ -560,9 +561,7 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
       if (__any(alive && !more)) {  // single-step pairs (both items have one level): final here
         const double score = ratio_of(la, lb, lcs) * 0.5;
         const bool hit = alive && !more && score >= p.threshold;
-        if (__any(hit)) {
-          if (hit) emit_hit(hits, p.cap, count, score, lorig[ib + r], jorig);
-        }
+        emit_hits_wave(hits, p.cap, count, hit, score, lorig[ib + r], jorig);
       }
       const unsigned long long who = __ballot(more);
       if (who == 0ull) return;

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(kBlock) void indel_raw_wide_kernel(
   // layout: [wave][pm_stride * K] masks | [wave][16 K][64] text dwords | lcsmin
   const int waves = blockDim.x >> 6;  // 4 (K = 2), 2 (K = 4) or 1 (K = 8): keeps the block under 64 KiB of LDS
   unsigned long long* pm_all = s_mem;
-  uint32_t* text_all = reinterpret_cast<uint32_t*>(pm_all + waves * p.pm_stride * K);
+  uint32_t* text_all = reinterpret_cast<uint32_t*>(pm_all + waves * p.pm_stride * kPmWords<K>);
   uint16_t* s_lcsmin = reinterpret_cast<uint16_t*>(text_all + waves * 16 * K * kWave);
   for (int t = threadIdx.x; t < 2 * kMaxLen + 4; t += blockDim.x) s_lcsmin[t] = p.lcsmin[t];
   __syncthreads();
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(kBlock) void indel_raw_wide_kernel(
   const bool valid = j < p.n_right;
   const int jc = valid ? j : p.n_right - 1;
 
-  unsigned long long* pm = pm_all + wave * p.pm_stride * K;
+  unsigned long long* pm = pm_all + wave * p.pm_stride * kPmWords<K>;
   uint32_t* text = text_all + wave * 16 * K * kWave;
   wide_store_text<K>(text, rcodes + static_cast<size_t>(jc) * kMaxLen, lane);
   const int lbj = valid ? rlen[jc] : 0;
@@ -113,7 +113,7 @@ static int launch_wide(const nsm_str_table* left, const nsm_str_table* right, do
   constexpr int kMaxLen = kWave * K;
   IndelWideParams p;
   p.n_left = left->n; p.n_right = right->n; p.cap = capacity;
-  p.pm_stride = ((left->alphabet + 1) + 63) / 64 * 64;
+  p.pm_stride = ((left->alphabet + 1) + 7) / 8 * 8;  // entries per mask table (the pad symbol included)
   p.zero_need = (0.0 >= threshold) ? 0 : kNeverWide;
   for (int s = 0; s < 1032; ++s) {
     p.lcsmin[s] = kNeverWide;
@@ -138,7 +138,7 @@ static int launch_wide(const nsm_str_table* left, const nsm_str_table* right, do
     p.rows_per_chunk = (left->n + 65534) / 65535;
     grid.y = (left->n + p.rows_per_chunk - 1) / p.rows_per_chunk;
   }
-  const size_t lds = static_cast<size_t>(kWaves) * (p.pm_stride * K * 8 + 16 * K * kWave * 4) +
+  const size_t lds = static_cast<size_t>(kWaves) * (p.pm_stride * kPmWords<K> * 8 + 16 * K * kWave * 4) +
                      (2 * kMaxLen + 4) * 2 + 16;
   const uint32_t* lh = reinterpret_cast<const uint32_t*>(left->hist);
   const uint32_t* rh = reinterpret_cast<const uint32_t*>(right->hist);

@@ -5,7 +5,7 @@
 // score_func: fuzzy_match; config.yml:13-14) takes; the one-word kernels are the fast case.
 //
 // Layout per wavefront in LDS:
-//   pm    [pm_stride][K] u64   match masks of the wave-uniform pattern, K words per symbol
+//   pm    [pm_stride][K + 1] u64   match masks of the wave-uniform pattern, K words per symbol + 1 of padding
 //   text  [16 K][64]     u32   the lanes' texts, 4 code units per dword, column = lane (conflict-free)
 // Hyyro's update with a carry chain across the words:
 //   U_k = V_k & PM[c][k];  (V + U) over K words with carry;  V_k = sum_k | (V_k ^ U_k)
@@ -16,11 +16,18 @@ namespace nsm {
 
 constexpr uint16_t kNeverWide = 0xffff;
 
+// 64-bit words per mask-table entry.  K > 1: one word of padding, so that the entries of different symbols
+// start in different LDS banks (entry stride (K + 1) * 2 dwords: 32 symbols without a conflict; at stride
+// 2 K dwords symbols c and c + 32 / K collide -- measured on Term-like strings: 62 % of the LDS cycles of the
+// levels kernel were bank conflicts of these reads)
+template <int K>
+constexpr int kPmWords = K == 1 ? 1 : K + 1;
+
 // Build the wave's match-mask table for the pattern row `codes` (la code units).
 template <int K>
 __device__ __forceinline__ void wide_build_pm(unsigned long long* pm, int pm_stride, const uint8_t* __restrict__ codes,
                                               int la, int lane) {
-  for (int c = lane; c < pm_stride * K; c += kWave) pm[c] = 0ull;
+  for (int c = lane; c < pm_stride * kPmWords<K>; c += kWave) pm[c] = 0ull;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -28,7 +35,7 @@ __device__ __forceinline__ void wide_build_pm(unsigned long long* pm, int pm_str
     const int pos = lane + kWave * k;
     if (pos < la) {
       const unsigned c = codes[pos];
-      atomicOr(&pm[c * K + k], 1ull << lane);
+      atomicOr(&pm[c * kPmWords<K> + k], 1ull << lane);
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -122,7 +129,7 @@ __device__ __forceinline__ int wide_lcs_words(const unsigned long long* pm, cons
   auto load_masks = [&](uint32_t word, unsigned long long (&m)[4][W]) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      const unsigned long long* e = pm + ((word >> (8 * b)) & 0xffu) * K;
+      const unsigned long long* e = pm + ((word >> (8 * b)) & 0xffu) * kPmWords<K>;
 #pragma unroll
       for (int k = 0; k < W; ++k) m[b][k] = e[k];
     }

@@ -31,6 +31,35 @@ __device__ __forceinline__ void emit_hit(nsm_hit* __restrict__ hits, unsigned lo
 
 __device__ __forceinline__ int wave_first(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// Append the hits of a whole wavefront with ONE atomic on the counter: every lane calls this (all 64 enabled),
+// `hit` says whether the lane has a record.  At low thresholds millions of pairs hit (the reference's default
+// configuration keeps 2.6 % of them at cache_threshold 0.5) and one same-address atomic per record is then what
+// the kernel waits for.
+__device__ __forceinline__ void emit_hits_wave(nsm_hit* __restrict__ hits, unsigned long long cap,
+                                               unsigned long long* __restrict__ count, bool hit, double score, int i,
+                                               int j) {
+  const unsigned long long who = __ballot(hit);
+  if (who == 0ull) return;
+  const int leader = __builtin_ctzll(who);
+  const int lane = static_cast<int>(threadIdx.x & (kWave - 1));
+  unsigned long long base = 0;
+  if (lane == leader) base = atomicAdd(count, static_cast<unsigned long long>(__popcll(who)));
+  const uint32_t lo = __builtin_amdgcn_readlane(static_cast<uint32_t>(base), leader);
+  const uint32_t hi = __builtin_amdgcn_readlane(static_cast<uint32_t>(base >> 32), leader);
+  base = (static_cast<unsigned long long>(hi) << 32) | lo;
+  if (hit) {
+    const unsigned long long pos = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(who >> 32),
+                                                                     __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(who), 0u));
+    if (pos < cap) {
+      nsm_hit h;
+      h.score = score;
+      h.i = i;
+      h.j = j;
+      hits[pos] = h;
+    }
+  }
+}
+
 // Wave-wide max / or of a per-lane value, returned as a SCALAR (loops and branches on it stay on the
 // SALU).  Four DPP steps leave every 16-lane row with its own result, four v_readlane + SALU ops
 // combine the rows -- no LDS traffic, unlike the ds_bpermute chain __shfl_xor expands to.  Must be
