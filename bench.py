@@ -290,14 +290,11 @@ class Comm:
         """all-gatherv of the (score, i, j) hits.  RCCL has no native gatherv; the hit buffer carries its own
         counter in a trailing record (grid.HitBuffer), so ONE all-gather of the max-padded storage moves records
         and counts together.  Returns the work handle when ``async_op``."""
-        import torch
+        from napkon_string_matching_amd import distributed
 
-        if self.dev_group is None:  # gloo: stage through host memory
-            host = torch.empty((self.world * buf.storage.shape[0], 2), dtype=buf.storage.dtype)
-            self.dist.all_gather_into_tensor(host, buf.storage.cpu())
-            out.copy_(host.view_as(out))
-            return None
-        return self.dist.all_gather_into_tensor(out.view(-1, 2), buf.storage, group=self.dev_group, async_op=async_op)
+        # the product's exchange (ComparableData.gen_comparable under a process group) is this same function
+        _, work = distributed.all_gather_storage(buf.storage, out=out, group=self.dev_group, async_op=async_op)
+        return work
 
     def close(self):
         if self.dist is not None:
@@ -419,8 +416,6 @@ def run_c5(args, comm, device):
     import torch
 
     from napkon_string_matching_amd import _lib, distributed, grid, synthetic, tables
-    from napkon_string_matching_amd.compare import score_functions as sf
-
     rank, world = comm.rank, comm.world
     lib = _lib.load()
     rows = args.rows or 500_000
@@ -432,9 +427,12 @@ def run_c5(args, comm, device):
         cohorts[nm] = synthetic.c5_cohort(rows, 11 + k, plant_from=cohorts.get("hap"))
     pairs = [("hap", "pop"), ("hap", "suep"), ("pop", "suep")]
     lo, hi = distributed.shard_bounds(rows, rank, world)
+    # fuzzy_match operands (join_sorted + default_process of every level), as dense code units: generated
+    # vectorised -- the per-item Python strings of round 1 took longer than everything else together
     t0 = time.perf_counter()
-    level_strings = {nm: [[sf.fuzzy_operand(lv) for lv in it] for it in synthetic.c5_level_token_lists(c)]
-                     for nm, c in cohorts.items()}
+    level_codes = {nm: synthetic.c5_level_codes(c) for nm, c in cohorts.items()}
+    t_generate = time.perf_counter() - t0
+    t0 = time.perf_counter()
     grids = []
     for a, b in pairs:
         ca, cb = cohorts[a], cohorts[b]
@@ -443,8 +441,11 @@ def run_c5(args, comm, device):
                                                 orig=np.arange(lo, hi, dtype=np.int32))
         rt = tables.SetTable.from_nested_arrays(cb["ids"], cb["plen"], cb["nlev"], "right", device,
                                                 categories=cb["cat"], width=16, category_mode=mode)
-        li, ls, ri, rs = tables.encode_level_strings(level_strings[a][lo:hi], level_strings[b], device, ca["cat"][lo:hi],
-                                                     cb["cat"], mode, left_offset=lo)
+        codes_a, len_a, first_a, nlev_a = level_codes[a]
+        e = ca["entries"]
+        left_levels = (codes_a[lo * e: hi * e], len_a[lo * e: hi * e], first_a[lo:hi] - lo * e, nlev_a[lo:hi])
+        li, ls, ri, rs = tables.encode_level_codes(left_levels, level_codes[b], len(synthetic.C5_ALPHABET), device,
+                                                   ca["cat"][lo:hi], cb["cat"], mode, left_offset=lo)
         grids.append(("jaccard", (lt, rt), (lt.struct(), rt.struct()), lt.category_mode))
         grids.append(("indel", (li, ls, ri, rs), (li.struct(), ls.struct(), ri.struct(), rs.struct()), li.category_mode))
     torch.cuda.synchronize(device)
@@ -551,6 +552,7 @@ def run_c5(args, comm, device):
             "sharding": f"left rows of every cohort pair block-sharded over {world} rank(s), right replicated, hits all-gathered",
             "exchange": comm.exchange,
             "encode_and_h2d_seconds_once": round(t_encode, 2),
+            "level_string_generation_seconds_once": round(t_generate, 2),
             "fuzzy_grids_ms_per_step": ms_indel,
             "jaccard_grids_ms_per_step": ms_jac,
         },

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define NSM_ABI_VERSION 1
+#define NSM_ABI_VERSION 2
 
 #define NSM_E_BADARG 10001   /* inconsistent sizes / unsupported width */
 #define NSM_E_UNSUPPORTED 10002
@@ -173,6 +173,50 @@ int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_table* left
                           const nsm_level_items* right, const nsm_str_table* right_strings,
                           double threshold, int32_t category_mode, uint32_t flags, nsm_hit* hits,
                           uint64_t capacity, unsigned long long* hit_count, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Builders: plain per-item arrays in device memory (in the CALLER's row order) -> a table the grid functions
+ * read, derived columns (signatures, filter records, histograms), the sort the grids rely on and the category
+ * partition included.  They replace the per-item half of the reference's preparation that the per-pair loop
+ * re-does for every pair (set(...), join_sorted: compare/score_functions.py:10-11,16-17,24-25) and what
+ * round 1 of this library left to its Python host (napkon_string_matching_amd/tables.py); a host in any
+ * language now only supplies ids / code units / lengths / levels / category masks.
+ *
+ *   `out`  a table struct whose pointer fields point to CALLER-ALLOCATED device arrays (cast away the const)
+ *          and whose scalar fields say how they are laid out: n = capacity in rows on entry, rows built on
+ *          return; width / max_levels / stride / alphabet as documented on the struct.  A partitioned table
+ *          has one row per (item, category of the item): sum of popcount(cat) rows (<= 64 n; in practice a few
+ *          per item).  Optional columns may be NULL (sig2, hist); required ones are checked.
+ *   They SORT (stable: ties stay in the caller's order), so the grids never see an unsorted table.
+ *   They synchronise `stream` before returning (row count and validation verdict live on the device) and
+ *   allocate their scratch stream-ordered (hipMallocAsync / hipFreeAsync): nothing is kept after the call.
+ *   Data errors (row wider than the table, duplicate id with NSM_BUILD_VALIDATE, code unit >= alphabet,
+ *   category bit 63 in use where "both empty" must become a category) return NSM_E_BADARG.
+ */
+#define NSM_BUILD_PARTITION 1u /* levels tables: one row per (item, category), rows grouped by category */
+#define NSM_BUILD_VALIDATE 2u  /* set tables: check that no id occurs twice in a row (O(width^2) per row) */
+#define NSM_BUILD_SORT 4u      /* string tables: sort by length descending and fill len_start (RAW grid);
+                                  without it rows stay in input order (levels mode: items index them) */
+
+/* Token-id set table.  ids_in device int32 [n][width_in]: ids >= 0 in any slots, negative = unused.  side: 0 =
+ * left (padding -1), 1 = right (padding -2).  Levels mode when nlev_in != NULL: plen_in device uint8
+ * [n][out->max_levels] (level l = the first plen[l] ids; entries past the last level are ignored), cat_in device
+ * uint64 [n] or NULL, category_mode as for the grid; with NSM_BUILD_PARTITION and NSM_CAT_INTERSECT_OR_BOTH_EMPTY
+ * the empty items become category 63 and the grid is then to be called with NSM_CAT_INTERSECT.  orig_in device
+ * int32 [n] or NULL (0 .. n-1): the ids reported in hits. */
+int nsm_build_set_table(const int32_t* ids_in, int32_t n, int32_t width_in, int32_t side, const int32_t* nlev_in,
+                        const uint8_t* plen_in, const uint64_t* cat_in, const int32_t* orig_in, int32_t category_mode,
+                        uint32_t flags, nsm_set_table* out, void* stream);
+
+/* Code-unit string table.  codes_in device uint8 [n][out->stride] (positions >= len are ignored and rewritten to
+ * the pad code out->alphabet), len_in device int32 [n]. */
+int nsm_build_str_table(const uint8_t* codes_in, const int32_t* len_in, const int32_t* orig_in, int32_t n, uint32_t flags,
+                        nsm_str_table* out, void* stream);
+
+/* Items whose levels are rows first .. first + nlev - 1 of an (unsorted) string table: sorted deeper items first,
+ * with NSM_BUILD_PARTITION grouped by category (as nsm_build_set_table). */
+int nsm_build_level_items(const int32_t* first_in, const int32_t* nlev_in, const uint64_t* cat_in, const int32_t* orig_in,
+                          int32_t n, int32_t category_mode, uint32_t flags, nsm_level_items* out, void* stream);
 
 /* In-place canonical ordering of the first min(*hit_count, capacity) hits:
  * score descending, then i, then j ascending.  `scratch` is a device buffer of the same capacity. */

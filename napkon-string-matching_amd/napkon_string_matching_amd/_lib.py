@@ -6,9 +6,10 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("NSM_HIP_LIBRARY", _HERE.parent / "csrc" / "libnsm_hip.so"))
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 FLAG_PRUNE = 1
 FLAG_WAVE_WIDE = 2  # nsm_indel_levels_grid without the block-cooperative parking (A/B runs, tests)
+BUILD_PARTITION, BUILD_VALIDATE, BUILD_SORT = 1, 2, 4
 CAT_NONE, CAT_INTERSECT, CAT_INTERSECT_OR_BOTH_EMPTY = 0, 1, 2
 
 c_i32p = ctypes.c_void_p  # device pointers travel as integers
@@ -72,6 +73,9 @@ EXPORTS = (
     "nsm_indel_raw_grid",
     "nsm_indel_levels_grid",
     "nsm_sort_hits",
+    "nsm_build_set_table",
+    "nsm_build_str_table",
+    "nsm_build_level_items",
 )
 
 _lib = None
@@ -106,6 +110,10 @@ def load() -> ctypes.CDLL:
         P(NsmLevelItems), P(NsmStrTable), P(NsmLevelItems), P(NsmStrTable),
         ctypes.c_double, ctypes.c_int32, ctypes.c_uint32] + grid_tail
     lib.nsm_sort_hits.argtypes = [ctypes.c_void_p, ctypes.c_void_p, c_u64, ctypes.c_void_p, ctypes.c_void_p]
+    vp, i32, u32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32
+    lib.nsm_build_set_table.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, i32, u32, P(NsmSetTable), vp]
+    lib.nsm_build_str_table.argtypes = [vp, vp, vp, i32, u32, P(NsmStrTable), vp]
+    lib.nsm_build_level_items.argtypes = [vp, vp, vp, vp, i32, i32, u32, P(NsmLevelItems), vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("nsm_last_error",):

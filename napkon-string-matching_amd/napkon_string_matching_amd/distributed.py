@@ -4,8 +4,9 @@
 The grid shards naturally -- every pair's score depends on item i and item j only -- so the LEFT
 rows are split into contiguous blocks, the right side is replicated and there is no collective on
 the data path.  The only exchange is at the end: an all-gatherv of the above-threshold
-``(score, i, j)`` records (RCCL has no native gatherv: all-gather of the counts, then all-gather of
-max-padded buffers).  Volumes are tiny next to xGMI bandwidth (16 B per hit).
+``(score, i, j)`` records.  RCCL has no native gatherv: the hit buffer carries its counter in a trailing
+record, so ONE all-gather of the max-padded storage moves records and counts (``all_gather_storage`` --
+the same function ``bench.py`` measures).  Volumes are tiny next to xGMI bandwidth (16 B per hit).
 """
 from __future__ import annotations
 
@@ -31,33 +32,78 @@ def shard_bounds(n: int, rank: int, world_size: int) -> Tuple[int, int]:
     return lo, min(n, lo + per)
 
 
+def all_gather_storage(storage: torch.Tensor, out: Optional[torch.Tensor] = None, group=None, async_op: bool = False):
+    """THE exchange step of a sharded grid: one all-gather of a hit buffer's ``storage`` -- ``capacity`` 16-byte
+    ``(score f64, i i32, j i32)`` records followed by one record whose first 8 bytes are the hit counter
+    (``grid.HitBuffer``), viewed as float64 ``[capacity + 1][2]`` -- so records and counts travel together and
+    no second collective is needed (RCCL has no gatherv).  Every rank passes the same shape.
+
+    With an RCCL group the tensors stay on the device (``out``: ``[world][capacity + 1][2]`` on the same
+    device, allocated when omitted); with gloo the buffer is staged through host memory.  Returns
+    ``(out, work)``; ``work`` is the handle of an ``async_op`` RCCL gather, else None.  ``bench.py`` and
+    ``ComparableData.gen_comparable`` both go through here."""
+    import torch.distributed as dist
+
+    size = dist.get_world_size(group)
+    backend = dist.get_backend(group)
+    if out is None:
+        out = torch.empty((size,) + tuple(storage.shape), dtype=storage.dtype, device=storage.device)
+    if backend == "nccl":
+        work = dist.all_gather_into_tensor(out.view(-1, storage.shape[-1]), storage, group=group, async_op=async_op)
+        return out, (work if async_op else None)
+    host = torch.empty((size * storage.shape[0], storage.shape[1]), dtype=storage.dtype)
+    dist.all_gather_into_tensor(host, storage.detach().cpu().contiguous(), group=group)
+    out.copy_(host.view_as(out))
+    return out, None
+
+
+def pack_hits(score: np.ndarray, i: np.ndarray, j: np.ndarray, capacity: int) -> torch.Tensor:
+    """Host arrays -> the wire format of ``all_gather_storage`` (``capacity`` >= len(score))."""
+    n = len(score)
+    rec = np.zeros((capacity + 1, 2), dtype=np.float64)
+    rec[:n, 0] = score
+    ij = rec.view(np.int32).reshape(capacity + 1, 4)
+    ij[:n, 2], ij[:n, 3] = i, j
+    rec.view(np.int64).reshape(capacity + 1, 2)[capacity, 0] = n
+    return torch.from_numpy(rec)
+
+
+def unpack_storage(gathered: torch.Tensor) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """``[world][capacity + 1][2]`` float64 -> the valid records of every rank, concatenated in rank order."""
+    g = gathered.detach().cpu().numpy()
+    cap = g.shape[1] - 1
+    counts = g.view(np.int64).reshape(g.shape[0], cap + 1, 2)[:, cap, 0]
+    ij = g.view(np.int32).reshape(g.shape[0], cap + 1, 4)
+    parts_s, parts_i, parts_j = [], [], []
+    for r in range(g.shape[0]):
+        n = int(min(max(counts[r], 0), cap))
+        parts_s.append(g[r, :n, 0])
+        parts_i.append(ij[r, :n, 2])
+        parts_j.append(ij[r, :n, 3])
+    return np.concatenate(parts_s), np.concatenate(parts_i).astype(np.int64), np.concatenate(parts_j).astype(np.int64)
+
+
 def all_gather_hits(
     score: np.ndarray, i: np.ndarray, j: np.ndarray, device: Optional[torch.device] = None
 ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """Every rank contributes its local hits and receives all of them, in the canonical order
-    (score descending, i, j ascending).  ``i`` must already be GLOBAL left indices."""
+    (score descending, i, j ascending).  ``i`` must already be GLOBAL left indices (< 2^31).
+
+    The ranks first agree on the padded capacity (one 8-byte MAX all-reduce), then the records and their
+    counts move in the single all-gather of ``all_gather_storage``."""
     import torch.distributed as dist
 
     rank, size = world()
     if size == 1:
         order = np.lexsort((j, i, -score))
         return score[order], i[order], j[order]
+    on_device = dist.get_backend() == "nccl"
     if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-    n = len(score)
-    counts = torch.zeros(size, dtype=torch.int64, device=device)
-    mine = torch.tensor([n], dtype=torch.int64, device=device)
-    dist.all_gather_into_tensor(counts, mine)
-    counts_h = counts.cpu().numpy()
-    cap = max(1, int(counts_h.max()))
-    rec = np.zeros((cap, 3), dtype=np.float64)  # score, i, j (indices are exact in a double)
-    rec[:n, 0], rec[:n, 1], rec[:n, 2] = score, i, j
-    local = torch.from_numpy(rec).to(device)
-    gathered = torch.empty((size * cap, 3), dtype=torch.float64, device=device)
-    dist.all_gather_into_tensor(gathered, local)
-    g = gathered.cpu().numpy().reshape(size, cap, 3)
-    parts = [g[r, : int(counts_h[r])] for r in range(size)]
-    allrec = np.concatenate(parts, axis=0) if parts else np.zeros((0, 3))
-    s, gi, gj = allrec[:, 0], allrec[:, 1].astype(np.int64), allrec[:, 2].astype(np.int64)
+        device = torch.device("cuda", torch.cuda.current_device()) if on_device else torch.device("cpu")
+    cap = torch.tensor([len(score)], dtype=torch.int64, device=device)
+    dist.all_reduce(cap, op=dist.ReduceOp.MAX)
+    capacity = max(1, int(cap.item()))
+    gathered, _ = all_gather_storage(pack_hits(score, i, j, capacity).to(device))
+    s, gi, gj = unpack_storage(gathered)
     order = np.lexsort((gj, gi, -s))
     return s[order], gi[order], gj[order]

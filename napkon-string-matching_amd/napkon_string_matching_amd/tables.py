@@ -86,6 +86,21 @@ def _dev(array: np.ndarray, device) -> torch.Tensor:
     return torch.from_numpy(np.ascontiguousarray(array)).to(device)
 
 
+def _on_gpu(device) -> bool:
+    """Tables for a HIP device are built by the library's device-side builders (nsm_build_*: derived columns,
+    sorts, category partition); the numpy encoders below remain for host-side tables (CPU tests, and as the
+    parity reference of the builders: tests/test_gpu_builders.py)."""
+    return torch.device(device).type == "cuda"
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(device) -> int:
+    return torch.cuda.current_stream(torch.device(device)).cuda_stream
+
+
 class Vocabulary:
     """Equality-preserving token -> dense int32 id map shared by both sides of a grid."""
 
@@ -324,6 +339,8 @@ class SetTable:
                 category_mode=_lib.CAT_NONE, partition=False):
         if side not in ("left", "right"):
             raise ValueError("side must be 'left' or 'right'")
+        if _on_gpu(device):
+            return cls._finish_device(ids, cnt, side, device, width, orig, nlev, plen, cat, max_levels, category_mode, partition)
         n = ids.shape[0]
         ids = ids.copy()
         pad = LEFT_PAD if side == "left" else RIGHT_PAD
@@ -398,6 +415,54 @@ class SetTable:
             seg_start=None if seg_start is None else _dev(seg_start, device),
             category_mode=mode if nlev is not None else None,
         )
+
+    @classmethod
+    def _finish_device(cls, ids, cnt, side, device, width, orig, nlev, plen, cat, max_levels, category_mode, partition):
+        """The same table as ``_finish``, built on the GPU by ``nsm_build_set_table`` from the packed ids."""
+        lib = _lib.load()
+        n = ids.shape[0]
+        levels = nlev is not None
+        mode = category_mode if (levels and cat is not None) else _lib.CAT_NONE
+        do_part = mode != _lib.CAT_NONE and partition
+        rows, out_mode = n, mode
+        if cat is not None:
+            cat = np.asarray(cat, dtype=np.uint64)
+        if do_part:
+            c = cat.copy()
+            if mode == _lib.CAT_INTERSECT_OR_BOTH_EMPTY:
+                if not partition_allowed(mode, cat):
+                    raise ValueError(
+                        "category bit 63 is in use, so the empty items cannot become a category of their own: "
+                        "encode BOTH sides with partition=False (tables.partition_allowed decides for a pair)")
+                c[c == 0] = np.uint64(1) << np.uint64(EMPTY_CATEGORY_BIT)
+                out_mode = _lib.CAT_INTERSECT
+            rows = int(np.bitwise_count(c).sum())
+        dev = torch.device(device)
+        new = lambda shape, dtype: torch.empty(shape, dtype=dtype, device=dev)
+        t = cls(
+            ids=new((max(rows, 1), width), torch.int32)[:rows], cnt=new(max(rows, 1), torch.int32)[:rows],
+            sig=new(max(rows, 1), torch.int64)[:rows], orig=new(max(rows, 1), torch.int32)[:rows], side=side, width=width,
+            n=rows, has_empty=bool(n and int(np.min(cnt)) == 0), sig2=new(max(rows, 1), torch.int64)[:rows],
+            size_start=new(width + 2, torch.int32),
+            nlev=new(max(rows, 1), torch.int32)[:rows] if levels else None,
+            plen=new((max(rows, 1), max_levels), torch.uint8)[:rows] if levels else None,
+            cat=new(max(rows, 1), torch.int64)[:rows] if (levels and cat is not None) else None,
+            filt=new((max(rows, 1), 8), torch.int32)[:rows] if levels else None,
+            max_levels=max_levels, seg=new(max(rows, 1), torch.int32)[:rows] if do_part else None,
+            seg_start=new(65, torch.int32) if do_part else None, category_mode=out_mode if levels else None,
+        )
+        d_ids = _dev(np.asarray(ids, dtype=np.int32), dev)
+        d_nlev = _dev(np.asarray(nlev, dtype=np.int32), dev) if levels else None
+        d_plen = _dev(np.asarray(plen, dtype=np.uint8), dev) if levels else None
+        d_cat = _dev(cat.view(np.int64), dev) if (levels and cat is not None) else None
+        d_orig = None if orig is None else _dev(np.asarray(orig, dtype=np.int32), dev)
+        st = t.struct()
+        flags = _lib.BUILD_PARTITION if do_part else 0
+        _lib.check(lib.nsm_build_set_table(_ptr(d_ids), n, ids.shape[1], 0 if side == "left" else 1, _ptr(d_nlev), _ptr(d_plen),
+                                           _ptr(d_cat), _ptr(d_orig), mode, flags, st, _stream(dev)), "nsm_build_set_table")
+        if st.n != rows:
+            raise _lib.NsmLibraryError(f"nsm_build_set_table built {st.n} rows, expected {rows}")
+        return t
 
     # ------------------------------------------------------------------ C view
     def struct(self) -> _lib.NsmSetTable:
@@ -490,6 +555,8 @@ class StrTable:
             raise NotImplementedError(f"string longer than its row ({stride} code units)")
         if not 1 <= alphabet <= 255:
             raise ValueError("alphabet must be in [1, 255]")
+        if _on_gpu(device):
+            return cls._from_codes_device(codes, lengths, alphabet, device, orig, sort)
         codes = codes.copy()
         codes[np.arange(stride, dtype=np.int32)[None, :] >= lengths[:, None]] = alphabet
         if n and int(codes.max()) > alphabet:
@@ -518,6 +585,29 @@ class StrTable:
             alphabet=alphabet,
             has_empty=bool(n and lengths.min() == 0),
         )
+
+    @classmethod
+    def _from_codes_device(cls, codes, lengths, alphabet, device, orig, sort):
+        """The same table as the numpy path of ``from_codes``, built on the GPU by ``nsm_build_str_table``."""
+        lib = _lib.load()
+        n, stride = codes.shape
+        dev = torch.device(device)
+        new = lambda shape, dtype: torch.empty(shape, dtype=dtype, device=dev)
+        t = cls(codes=new((max(n, 1), stride), torch.uint8)[:n], len=new(max(n, 1), torch.int32)[:n],
+                orig=new(max(n, 1), torch.int32)[:n], n=n, stride=stride, alphabet=alphabet,
+                has_empty=bool(n and int(lengths.min()) == 0), hist=new((max(n, 1), 32), torch.uint8)[:n],
+                len_start=new(stride + 2, torch.int32) if sort else None)
+        d_codes, d_len = _dev(codes, dev), _dev(lengths, dev)
+        d_orig = None if orig is None else _dev(np.asarray(orig, dtype=np.int32), dev)
+        st = t.struct()
+        try:
+            _lib.check(lib.nsm_build_str_table(_ptr(d_codes), _ptr(d_len), _ptr(d_orig), n, _lib.BUILD_SORT if sort else 0, st,
+                                               _stream(dev)), "nsm_build_str_table")
+        except _lib.NsmLibraryError as exc:
+            if "code unit outside the alphabet" in str(exc):
+                raise ValueError("code unit outside the alphabet") from exc
+            raise
+        return t
 
     @classmethod
     def from_strings(cls, strings: Sequence[str], alphabet: Alphabet, device, sort: bool = True,
@@ -574,6 +664,31 @@ class LevelItems:
         )
 
 
+def _level_items_device(first, nlev, cat, offset, mode, do_partition, device) -> "LevelItems":
+    """``LevelItems`` built on the GPU by ``nsm_build_level_items`` (``cat`` already carries bit 63 for the
+    empty items when the partition turned "both empty" into a category)."""
+    lib = _lib.load()
+    n = len(first)
+    dev = torch.device(device)
+    rows = int(np.bitwise_count(cat).sum()) if do_partition else n
+    new = lambda shape, dtype: torch.empty(shape, dtype=dtype, device=dev)
+    li = LevelItems(first=new(max(rows, 1), torch.int32)[:rows], nlev=new(max(rows, 1), torch.int32)[:rows],
+                    orig=new(max(rows, 1), torch.int32)[:rows], cat=None if cat is None else new(max(rows, 1), torch.int64)[:rows],
+                    n=rows, seg=new(max(rows, 1), torch.int32)[:rows] if do_partition else None,
+                    seg_start=new(65, torch.int32) if do_partition else None, category_mode=mode)
+    d_first, d_nlev = _dev(first, dev), _dev(nlev, dev)
+    d_cat = None if cat is None else _dev(np.asarray(cat, dtype=np.uint64).view(np.int64), dev)
+    d_orig = _dev((np.arange(n, dtype=np.int32) + offset).astype(np.int32), dev) if offset else None
+    st = li.struct()
+    # the mode the builder sees is the one AFTER the rewrite: the caller already folded "both empty" into bit 63
+    _lib.check(lib.nsm_build_level_items(_ptr(d_first), _ptr(d_nlev), _ptr(d_cat), _ptr(d_orig), n,
+                                         _lib.CAT_INTERSECT if cat is not None else _lib.CAT_NONE,
+                                         _lib.BUILD_PARTITION if do_partition else 0, st, _stream(dev)), "nsm_build_level_items")
+    if st.n != rows:
+        raise _lib.NsmLibraryError(f"nsm_build_level_items built {st.n} rows, expected {rows}")
+    return li
+
+
 def encode_level_strings(
     left_items: Sequence[Sequence[str]], right_items: Sequence[Sequence[str]], device,
     left_cat: Optional[np.ndarray] = None, right_cat: Optional[np.ndarray] = None,
@@ -590,6 +705,33 @@ def encode_level_strings(
     """
     alpha = Alphabet(s for items in (left_items, right_items) for levels in items for s in levels)
     stride = pick_stride(max((len(s) for items in (left_items, right_items) for lv in items for s in lv), default=0))
+
+    def flatten(items):
+        flat: List[str] = []
+        first = np.zeros(len(items), dtype=np.int32)
+        nlev = np.zeros(len(items), dtype=np.int32)
+        for k, levels in enumerate(items):
+            if len(levels) > MAX_LEVELS:
+                raise NotImplementedError(f"item {k} has {len(levels)} levels > {MAX_LEVELS}")
+            first[k] = len(flat)
+            nlev[k] = len(levels)
+            flat.extend(levels)
+        codes, lengths = alpha.encode(flat, stride)
+        return codes, lengths, first, nlev
+
+    return encode_level_codes(flatten(left_items), flatten(right_items), alpha.size, device, left_cat, right_cat,
+                              category_mode, partition, left_offset)
+
+
+def encode_level_codes(
+    left, right, alphabet: int, device, left_cat: Optional[np.ndarray] = None, right_cat: Optional[np.ndarray] = None,
+    category_mode: int = _lib.CAT_NONE, partition: bool = True, left_offset: int = 0,
+):
+    """``encode_level_strings`` for operands that already are dense code units: ``left`` / ``right`` =
+    ``(codes uint8 [rows][stride], lengths int32 [rows], first int32 [n], nlev int32 [n])`` over ONE alphabet of
+    ``alphabet`` symbols and one stride; level l of item k is row ``first[k] + l``."""
+    if left[0].shape[1] != right[0].shape[1]:
+        raise ValueError("both sides must use the same row stride")
     use_cat = category_mode != _lib.CAT_NONE and left_cat is not None and right_cat is not None
     mode = category_mode if use_cat else _lib.CAT_NONE
     cats = {}
@@ -606,18 +748,15 @@ def encode_level_strings(
                     mode = _lib.CAT_INTERSECT
     do_partition = use_cat and partition
 
-    def side(items, cat, offset=0):
-        flat: List[str] = []
-        first = np.zeros(len(items), dtype=np.int32)
-        nlev = np.zeros(len(items), dtype=np.int32)
-        for k, levels in enumerate(items):
-            if len(levels) > MAX_LEVELS:
-                raise NotImplementedError(f"item {k} has {len(levels)} levels > {MAX_LEVELS}")
-            first[k] = len(flat)
-            nlev[k] = len(levels)
-            flat.extend(levels)
-        table = StrTable.from_strings(flat, alpha, device, sort=False, stride=stride)
-        item = np.arange(len(items), dtype=np.int32)
+    def side(operand, cat, offset=0):
+        codes, lengths, first, nlev = operand
+        first, nlev = np.asarray(first, dtype=np.int32), np.asarray(nlev, dtype=np.int32)
+        if len(nlev) and int(nlev.max()) > MAX_LEVELS:
+            raise NotImplementedError(f"an item has {int(nlev.max())} levels > {MAX_LEVELS}")
+        table = StrTable.from_codes(codes, lengths, alphabet, device, sort=False)
+        if _on_gpu(device):
+            return _level_items_device(first, nlev, cat, offset, mode, do_partition, device), table
+        item = np.arange(len(first), dtype=np.int32)
         seg = seg_start = None
         if do_partition:
             rows, segs = [], []
@@ -643,6 +782,6 @@ def encode_level_strings(
         )
         return li, table
 
-    l_items, l_table = side(left_items, cats.get("l"), left_offset)
-    r_items, r_table = side(right_items, cats.get("r"))
+    l_items, l_table = side(left, cats.get("l"), left_offset)
+    r_items, r_table = side(right, cats.get("r"))
     return l_items, l_table, r_items, r_table
