@@ -39,14 +39,14 @@ struct Status {
 
 struct Scratch {  // stream-ordered allocations of one builder call
   hipStream_t stream;
-  void* ptr[16];
+  void* ptr[48];
   int n = 0;
   bool failed = false;
   explicit Scratch(hipStream_t s) : stream(s) {}
   template <typename T>
   T* get(size_t count) {
     void* p = nullptr;
-    if (n >= 16 || hipMallocAsync(&p, (count ? count : 1) * sizeof(T), stream) != hipSuccess) {
+    if (n >= 48 || hipMallocAsync(&p, (count ? count : 1) * sizeof(T), stream) != hipSuccess) {
       failed = true;
       return nullptr;
     }

@@ -339,6 +339,10 @@ class SetTable:
                 category_mode=_lib.CAT_NONE, partition=False):
         if side not in ("left", "right"):
             raise ValueError("side must be 'left' or 'right'")
+        if nlev is not None:  # entries of plen past an item's last level repeat it (the clamped level index)
+            plen = np.asarray(plen, dtype=np.uint8)
+            clamp = np.minimum(np.arange(plen.shape[1])[None, :], np.maximum(np.asarray(nlev), 1)[:, None] - 1)
+            plen = np.take_along_axis(plen, clamp, axis=1)
         if _on_gpu(device):
             return cls._finish_device(ids, cnt, side, device, width, orig, nlev, plen, cat, max_levels, category_mode, partition)
         n = ids.shape[0]
@@ -438,17 +442,18 @@ class SetTable:
                 out_mode = _lib.CAT_INTERSECT
             rows = int(np.bitwise_count(c).sum())
         dev = torch.device(device)
+        cap = max(rows, 1)  # (an empty tensor has no data pointer: columns are allocated with one row at least)
         new = lambda shape, dtype: torch.empty(shape, dtype=dtype, device=dev)
         t = cls(
-            ids=new((max(rows, 1), width), torch.int32)[:rows], cnt=new(max(rows, 1), torch.int32)[:rows],
-            sig=new(max(rows, 1), torch.int64)[:rows], orig=new(max(rows, 1), torch.int32)[:rows], side=side, width=width,
-            n=rows, has_empty=bool(n and int(np.min(cnt)) == 0), sig2=new(max(rows, 1), torch.int64)[:rows],
+            ids=new((cap, width), torch.int32), cnt=new(cap, torch.int32),
+            sig=new(cap, torch.int64), orig=new(cap, torch.int32), side=side, width=width,
+            n=rows, has_empty=bool(n and int(np.min(cnt)) == 0), sig2=new(cap, torch.int64),
             size_start=new(width + 2, torch.int32),
-            nlev=new(max(rows, 1), torch.int32)[:rows] if levels else None,
-            plen=new((max(rows, 1), max_levels), torch.uint8)[:rows] if levels else None,
-            cat=new(max(rows, 1), torch.int64)[:rows] if (levels and cat is not None) else None,
-            filt=new((max(rows, 1), 8), torch.int32)[:rows] if levels else None,
-            max_levels=max_levels, seg=new(max(rows, 1), torch.int32)[:rows] if do_part else None,
+            nlev=new(cap, torch.int32) if levels else None,
+            plen=new((cap, max_levels), torch.uint8) if levels else None,
+            cat=new(cap, torch.int64) if (levels and cat is not None) else None,
+            filt=new((cap, 8), torch.int32) if levels else None,
+            max_levels=max_levels, seg=new(cap, torch.int32) if do_part else None,
             seg_start=new(65, torch.int32) if do_part else None, category_mode=out_mode if levels else None,
         )
         d_ids = _dev(np.asarray(ids, dtype=np.int32), dev)
@@ -462,6 +467,9 @@ class SetTable:
                                            _ptr(d_cat), _ptr(d_orig), mode, flags, st, _stream(dev)), "nsm_build_set_table")
         if st.n != rows:
             raise _lib.NsmLibraryError(f"nsm_build_set_table built {st.n} rows, expected {rows}")
+        for col in ("ids", "cnt", "sig", "sig2", "orig", "nlev", "plen", "cat", "filt", "seg"):
+            if getattr(t, col) is not None:
+                setattr(t, col, getattr(t, col)[:rows])
         return t
 
     # ------------------------------------------------------------------ C view
@@ -593,9 +601,10 @@ class StrTable:
         n, stride = codes.shape
         dev = torch.device(device)
         new = lambda shape, dtype: torch.empty(shape, dtype=dtype, device=dev)
-        t = cls(codes=new((max(n, 1), stride), torch.uint8)[:n], len=new(max(n, 1), torch.int32)[:n],
-                orig=new(max(n, 1), torch.int32)[:n], n=n, stride=stride, alphabet=alphabet,
-                has_empty=bool(n and int(lengths.min()) == 0), hist=new((max(n, 1), 32), torch.uint8)[:n],
+        cap = max(n, 1)  # (an empty tensor has no data pointer)
+        t = cls(codes=new((cap, stride), torch.uint8), len=new(cap, torch.int32),
+                orig=new(cap, torch.int32), n=n, stride=stride, alphabet=alphabet,
+                has_empty=bool(n and int(lengths.min()) == 0), hist=new((cap, 32), torch.uint8),
                 len_start=new(stride + 2, torch.int32) if sort else None)
         d_codes, d_len = _dev(codes, dev), _dev(lengths, dev)
         d_orig = None if orig is None else _dev(np.asarray(orig, dtype=np.int32), dev)
@@ -607,6 +616,7 @@ class StrTable:
             if "code unit outside the alphabet" in str(exc):
                 raise ValueError("code unit outside the alphabet") from exc
             raise
+        t.codes, t.len, t.orig, t.hist = t.codes[:n], t.len[:n], t.orig[:n], t.hist[:n]
         return t
 
     @classmethod
@@ -672,9 +682,10 @@ def _level_items_device(first, nlev, cat, offset, mode, do_partition, device) ->
     dev = torch.device(device)
     rows = int(np.bitwise_count(cat).sum()) if do_partition else n
     new = lambda shape, dtype: torch.empty(shape, dtype=dtype, device=dev)
-    li = LevelItems(first=new(max(rows, 1), torch.int32)[:rows], nlev=new(max(rows, 1), torch.int32)[:rows],
-                    orig=new(max(rows, 1), torch.int32)[:rows], cat=None if cat is None else new(max(rows, 1), torch.int64)[:rows],
-                    n=rows, seg=new(max(rows, 1), torch.int32)[:rows] if do_partition else None,
+    cap = max(rows, 1)  # (an empty tensor has no data pointer)
+    li = LevelItems(first=new(cap, torch.int32), nlev=new(cap, torch.int32),
+                    orig=new(cap, torch.int32), cat=None if cat is None else new(cap, torch.int64),
+                    n=rows, seg=new(cap, torch.int32) if do_partition else None,
                     seg_start=new(65, torch.int32) if do_partition else None, category_mode=mode)
     d_first, d_nlev = _dev(first, dev), _dev(nlev, dev)
     d_cat = None if cat is None else _dev(np.asarray(cat, dtype=np.uint64).view(np.int64), dev)
@@ -686,6 +697,9 @@ def _level_items_device(first, nlev, cat, offset, mode, do_partition, device) ->
                                          _lib.BUILD_PARTITION if do_partition else 0, st, _stream(dev)), "nsm_build_level_items")
     if st.n != rows:
         raise _lib.NsmLibraryError(f"nsm_build_level_items built {st.n} rows, expected {rows}")
+    for col in ("first", "nlev", "orig", "cat", "seg"):
+        if getattr(li, col) is not None:
+            setattr(li, col, getattr(li, col)[:rows])
     return li
 
 
