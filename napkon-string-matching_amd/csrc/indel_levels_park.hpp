@@ -104,32 +104,6 @@ __device__ __forceinline__ float rest_bound(int s, int S, float ub) {
 }
 
 
-// One code unit of Hyyro's LCS recurrence, V' = (V + (V & M)) | (V ^ (V & M)), spelled as e32 instructions:
-// left to itself hipcc fuses the expression into three v_bitop3_b32 and an add per code unit, and VOP3 ops
-// issue at half the rate of e32 ops with VGPR operands (profiles/r01_valu_issue_rates_gfx950.txt).
-__device__ __forceinline__ uint32_t lcs_step32(uint32_t v, uint32_t m) {
-  uint32_t u, t, x, r;
-  asm("v_and_b32 %0, %1, %2" : "=v"(u) : "v"(v), "v"(m));
-  asm("v_add_u32 %0, %1, %2" : "=v"(t) : "v"(v), "v"(u));
-  asm("v_xor_b32 %0, %1, %2" : "=v"(x) : "v"(v), "v"(u));
-  asm("v_or_b32 %0, %1, %2" : "=v"(r) : "v"(t), "v"(x));
-  return r;
-}
-
-__device__ __forceinline__ unsigned long long lcs_step64(unsigned long long v, unsigned long long m) {
-  const uint32_t vl = static_cast<uint32_t>(v), vh = static_cast<uint32_t>(v >> 32);
-  const uint32_t ml = static_cast<uint32_t>(m), mh = static_cast<uint32_t>(m >> 32);
-  uint32_t ul, uh, xl, xh, rl, rh;
-  asm("v_and_b32 %0, %1, %2" : "=v"(ul) : "v"(vl), "v"(ml));
-  asm("v_and_b32 %0, %1, %2" : "=v"(uh) : "v"(vh), "v"(mh));
-  const unsigned long long t = lev_add64(v, (static_cast<unsigned long long>(uh) << 32) | ul);
-  asm("v_xor_b32 %0, %1, %2" : "=v"(xl) : "v"(vl), "v"(ul));
-  asm("v_xor_b32 %0, %1, %2" : "=v"(xh) : "v"(vh), "v"(uh));
-  asm("v_or_b32 %0, %1, %2" : "=v"(rl) : "v"(static_cast<uint32_t>(t)), "v"(xl));
-  asm("v_or_b32 %0, %1, %2" : "=v"(rh) : "v"(static_cast<uint32_t>(t >> 32)), "v"(xh));
-  return (static_cast<unsigned long long>(rh) << 32) | rl;
-}
-
 template <int K>
 __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
     const int32_t* __restrict__ lfirst, const int32_t* __restrict__ lnlev, const int32_t* __restrict__ lorig,

@@ -93,9 +93,16 @@ __global__ __launch_bounds__(kBlock) void indel_raw_kernel(
   // text as LDS addresses of the symbols' masks: two 16-bit fields per VGPR.  With the prune on,
   // LCS rows are rare (< 0.1 % of the rows a wave visits on C3), so the 32 registers are rebuilt
   // per LCS row instead of being kept live across the histogram loop (occupancy 4 -> 8 waves/SIMD).
+  // Patterns <= 32 read their masks with ds_read_b32: at the table's 8-byte stride those reads only touch
+  // the even LDS banks, symbols c and c + 16 collide (37 symbols over 16 banks: half of the exhaustive kernel's
+  // LDS cycles were bank conflicts, profiles/r02_before_c3_sq_pmc.txt).  The mask of a narrow pattern is
+  // therefore stored in BOTH halves of its entry and symbol c is read from half (c >> 4) & 1: symbols 0..31
+  // map to 32 different banks.  The half is baked into the text's addresses, which are rebuilt when the
+  // pattern class changes between wide and narrow (rows are sorted by length: once per chunk).
   uint32_t taddr[32];
-  auto build_taddr = [&]() {
+  auto build_taddr = [&](bool narrow) {
     const uint4* tp = reinterpret_cast<const uint4*>(rcodes + static_cast<size_t>(jc) * 64);
+    const uint32_t hsel = narrow ? 4u : 0u;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const uint4 v = tp[q];
@@ -103,12 +110,14 @@ __global__ __launch_bounds__(kBlock) void indel_raw_kernel(
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const uint32_t c0 = w[e] & 0xffu, c1 = (w[e] >> 8) & 0xffu, c2 = (w[e] >> 16) & 0xffu, c3 = w[e] >> 24;
-        taddr[8 * q + 2 * e + 0] = (pm_base + 8 * c0) | ((pm_base + 8 * c1) << 16);
-        taddr[8 * q + 2 * e + 1] = (pm_base + 8 * c2) | ((pm_base + 8 * c3) << 16);
+        const uint32_t a0 = pm_base + 8 * c0 + (((c0 >> 4) & 1u) ? hsel : 0u), a1 = pm_base + 8 * c1 + (((c1 >> 4) & 1u) ? hsel : 0u);
+        const uint32_t a2 = pm_base + 8 * c2 + (((c2 >> 4) & 1u) ? hsel : 0u), a3 = pm_base + 8 * c3 + (((c3 >> 4) & 1u) ? hsel : 0u);
+        taddr[8 * q + 2 * e + 0] = a0 | (a1 << 16);
+        taddr[8 * q + 2 * e + 1] = a2 | (a3 << 16);
       }
     }
   };
-  if (!PRUNE) build_taddr();
+  int taddr_narrow = -1;  // which variant the registers hold (exhaustive mode keeps them across rows)
   const int lbj = valid ? rlen[jc] : 0;
   const int jorig = rorig[jc];
   const int npairs = (wave_first(lbj) + 1) >> 1;  // sorted descending: lane 0 has the longest text
@@ -127,41 +136,51 @@ __global__ __launch_bounds__(kBlock) void indel_raw_kernel(
 
   // ---- LCS of pattern row i (length la, match masks built here) against the lane's text
   auto lcs_row = [&](int i, int la, bool wide) -> int {
-    if (PRUNE) build_taddr();
+    if (PRUNE || taddr_narrow != static_cast<int>(!wide)) {
+      build_taddr(!wide);
+      taddr_narrow = static_cast<int>(!wide);
+    }
     for (int c = lane; c < p.pm_stride; c += kWave) pm[c] = 0ull;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (lane < la) {
       const unsigned c = lcodes[static_cast<size_t>(i) * 64 + lane];
-      atomicOr(&pm[c], 1ull << lane);
+      atomicOr(&pm[c], wide ? (1ull << lane) : ((1ull << lane) | (1ull << (32 + lane))));  // narrow: both halves
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    // 8 code units per group: their mask reads are issued together (one LDS round trip per group instead of one
+    // per dependent step), the recurrence is spelled as e32 instructions (nsm_common.hpp: lcs_step32 / 64)
+    const int nchars = 2 * npairs;
     if (!wide) {  // pattern <= 32: 32-bit words, and / add / xor / or all issue at full rate
       uint32_t v = ~0u;
 #pragma unroll
-      for (int w = 0; w < 32; ++w) {
-        if (w < npairs) {
-          const uint32_t m0 = lds_load<uint32_t>(taddr[w] & lowmask);
-          const uint32_t u0 = v & m0;
-          v = (v + u0) | (v ^ u0);
-          const uint32_t m1 = lds_load<uint32_t>(taddr[w] >> 16);
-          const uint32_t u1 = v & m1;
-          v = (v + u1) | (v ^ u1);
+      for (int g = 0; g < 8; ++g) {
+        if (g * 8 < nchars) {
+          uint32_t m[8];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            m[2 * q] = lds_load<uint32_t>(taddr[4 * g + q] & lowmask);
+            m[2 * q + 1] = lds_load<uint32_t>(taddr[4 * g + q] >> 16);
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v = lcs_step32(v, m[q]);
         }
       }
       return 32 - __popc(v);
     }
     unsigned long long v = ~0ull;
 #pragma unroll
-    for (int w = 0; w < 32; ++w) {
-      if (w < npairs) {
-        const unsigned long long m0 = lds_load<unsigned long long>(taddr[w] & lowmask);
-        const unsigned long long u0 = v & m0;
-        v = add64(v, u0) | (v ^ u0);
-        const unsigned long long m1 = lds_load<unsigned long long>(taddr[w] >> 16);
-        const unsigned long long u1 = v & m1;
-        v = add64(v, u1) | (v ^ u1);
+    for (int g = 0; g < 8; ++g) {
+      if (g * 8 < nchars) {
+        unsigned long long m[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          m[2 * q] = lds_load<unsigned long long>(taddr[4 * g + q] & lowmask);
+          m[2 * q + 1] = lds_load<unsigned long long>(taddr[4 * g + q] >> 16);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v = lcs_step64(v, m[q]);
       }
     }
     return 64 - __popcll(v);

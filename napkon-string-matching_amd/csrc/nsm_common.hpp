@@ -91,6 +91,34 @@ __device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) 
   return (static_cast<unsigned long long>(hi) << 32) | lo;
 }
 
+// One code unit of Hyyro's LCS recurrence, V' = (V + (V & M)) | (V ^ (V & M)), spelled as e32 instructions:
+// left to itself hipcc fuses the expression into three v_bitop3_b32 and an add per code unit, and VOP3 ops
+// issue at half the rate of e32 ops with VGPR operands (profiles/r01_valu_issue_rates_gfx950.txt).
+__device__ __forceinline__ uint32_t lcs_step32(uint32_t v, uint32_t m) {
+  uint32_t u, t, x, r;
+  asm("v_and_b32 %0, %1, %2" : "=v"(u) : "v"(v), "v"(m));
+  asm("v_add_u32 %0, %1, %2" : "=v"(t) : "v"(v), "v"(u));
+  asm("v_xor_b32 %0, %1, %2" : "=v"(x) : "v"(v), "v"(u));
+  asm("v_or_b32 %0, %1, %2" : "=v"(r) : "v"(t), "v"(x));
+  return r;
+}
+
+__device__ __forceinline__ unsigned long long lcs_step64(unsigned long long v, unsigned long long m) {
+  const uint32_t vl = static_cast<uint32_t>(v), vh = static_cast<uint32_t>(v >> 32);
+  const uint32_t ml = static_cast<uint32_t>(m), mh = static_cast<uint32_t>(m >> 32);
+  uint32_t ul, uh, xl, xh, rl, rh;
+  asm("v_and_b32 %0, %1, %2" : "=v"(ul) : "v"(vl), "v"(ml));
+  asm("v_and_b32 %0, %1, %2" : "=v"(uh) : "v"(vh), "v"(mh));
+  unsigned long long t;  // one VALU op for the 64-bit add (v_add_co + v_addc_co issue in 9.3 cycles, this in 5.3)
+  asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(t) : "v"(v), "v"((static_cast<unsigned long long>(uh) << 32) | ul));
+  asm("v_xor_b32 %0, %1, %2" : "=v"(xl) : "v"(vl), "v"(ul));
+  asm("v_xor_b32 %0, %1, %2" : "=v"(xh) : "v"(vh), "v"(uh));
+  asm("v_or_b32 %0, %1, %2" : "=v"(rl) : "v"(static_cast<uint32_t>(t)), "v"(xl));
+  asm("v_or_b32 %0, %1, %2" : "=v"(rh) : "v"(static_cast<uint32_t>(t >> 32)), "v"(xh));
+  return (static_cast<unsigned long long>(rh) << 32) | rl;
+}
+
+
 __device__ __forceinline__ bool category_match(uint64_t cl, uint64_t cr, int mode) {
   // types/comparable_data.py:467-476; the predicate kind was chosen by the host from row 0.
   const bool inter = (cl & cr) != 0;

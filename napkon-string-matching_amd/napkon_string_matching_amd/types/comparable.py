@@ -111,7 +111,21 @@ class Comparable:
         return json.dumps(payload, **kwargs)
 
     def write_json(self, file_name) -> None:
-        Path(file_name).write_text(self.to_json(orient="records", indent=4), encoding="utf-8")
+        """Written to a temporary file and renamed into place: a concurrent reader (or a second writer of the
+        same content, e.g. another rank of a sharded run) never sees a truncated file."""
+        import os
+        import tempfile
+
+        target = Path(file_name)
+        fd, tmp = tempfile.mkstemp(prefix=target.name + ".", suffix=".tmp", dir=str(target.parent))
+        try:
+            with os.fdopen(fd, "w", encoding="utf-8") as handle:
+                handle.write(self.to_json(orient="records", indent=4))
+            os.replace(tmp, target)
+        except BaseException:
+            if os.path.exists(tmp):
+                os.unlink(tmp)
+            raise
 
     @classmethod
     def read_json(cls, file_name) -> "Comparable":

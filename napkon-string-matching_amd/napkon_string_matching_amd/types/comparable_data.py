@@ -353,7 +353,8 @@ class ComparableData:
                 identifier_column_right=identifier_column_right,
                 **kwargs,
             )
-            if cache_file is not None:
+            if cache_file is not None and distributed.world()[0] == 0:
+                # every rank of a sharded run holds the full result: rank 0 writes it (atomically, see write_json)
                 cache_file.parent.mkdir(parents=True, exist_ok=True)
                 logger.info("write cache to file")
                 result.write_json(cache_file)
