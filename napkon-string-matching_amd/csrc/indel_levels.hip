@@ -370,13 +370,17 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
     q.use_hist = ((flags & NSM_FLAG_PRUNE) && left_strings->hist && right_strings->hist) ? 1 : 0;
     q.pm_stride = (left_strings->alphabet + 1 + 7) / 8 * 8;
     const int batch = park_batch(K);
-    q.park_slots = 128;
-    q.park_max = 24;
+#ifndef NSM_PARK_MAX
+#define NSM_PARK_MAX 24
+#endif
+    q.park_slots = K == 1 ? 128 : 64;  // per region (kSub regions); multi-word blocks are short of LDS
+    q.park_max = NSM_PARK_MAX;
     q.rows_per_chunk = p.rows_per_chunk;
     const size_t tbl_bytes = static_cast<size_t>(q.pm_stride) * pm_words * 8;
     const size_t fixed_wave = (K > 1 ? 16 * K * kWave * 4 : 0) + batch * kWave * 2 +
                               batch * 3 * kHeadDwords * 4 + batch * kWave * K;
-    const size_t park_bytes = static_cast<size_t>(q.park_slots) * kSub * 16 + 66 * 16 + 8 + 4 * kSub * 4;
+    const int sub = park_sub(K);
+    const size_t park_bytes = static_cast<size_t>(q.park_slots) * sub * 16 + 66 * 16 + 8 + 4 * sub * 4;
     // one-word text images hold 16-bit LDS addresses: the block stays under 64 KiB (and so do the others)
     const size_t budget = 60 * 1024;
     int pw = 4;  // waves (= right tiles) per block: as many as fit with one mask table each ...

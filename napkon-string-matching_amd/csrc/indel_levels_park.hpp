@@ -46,7 +46,13 @@ struct ParkParams {
 };
 
 constexpr int park_batch(int K) { return K >= 4 ? 4 : 8; }
-constexpr int kSub = 4;  // scan batches (= park regions) between two barriers
+// scan batches between two block barriers, A/B-measured on C5-shaped cohorts (3 x 100k^2): 1 / 2 / 4 / 8 / 16 ->
+// 41.9 / 24.0 / 22.0 / 20.8 / 23.2 ms (park regions of 64 slots; 128 slots: the same)
+#ifndef NSM_KSUB
+#define NSM_KSUB 8
+#endif
+constexpr int park_sub(int K) { return K == 1 ? NSM_KSUB : 4; }  // scan batches (= park regions) between two barriers
+// (multi-word strings, Term-like 20k x 20k at 0.5: 4 -> 140 ms, 8 -> 158 ms)
 constexpr uint16_t kDeadNeed = 0xffff;
 #ifndef NSM_X_GROUPS
 #define NSM_X_GROUPS 8
@@ -122,6 +128,7 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_mem[];
   constexpr int kRow = kWave * K;      // code units per string row
   constexpr int kBatch = park_batch(K);
+  constexpr int kSub = park_sub(K);
   constexpr int NB = (K == 1) ? 4 : 8;  // histogram dwords per level string
   const int waves = blockDim.x >> 6;
   const int lane = threadIdx.x & (kWave - 1);
