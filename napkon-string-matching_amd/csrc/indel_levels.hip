@@ -373,7 +373,7 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
 #ifndef NSM_PARK_MAX
 #define NSM_PARK_MAX 24
 #endif
-    q.park_slots = K == 1 ? 128 : 64;  // per region (kSub regions); multi-word blocks are short of LDS
+    q.park_slots = 128;  // per region (park_sub(K) regions); 64 overflow on Term-like strings (140 -> 157 ms)
     q.park_max = NSM_PARK_MAX;
     q.rows_per_chunk = p.rows_per_chunk;
     const size_t tbl_bytes = static_cast<size_t>(q.pm_stride) * pm_words * 8;
