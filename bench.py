@@ -68,6 +68,7 @@ def parse_args():
     ap.add_argument("--rows", type=int, default=0, help="override rows per side per GPU (debug)")
     ap.add_argument("--right-rows", type=int, default=0, help="override the right side's rows (debug)")
     ap.add_argument("--threshold", type=float, default=None, help="override the workload's threshold (debug)")
+    ap.add_argument("--id-range", type=int, default=0, help="c2 / c4: draw token ids from [0, N) instead of 2^17 (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", type=int, default=0, help="1: replay each step as one captured hipGraph")
     ap.add_argument("--capacity", type=int, default=1 << 13)
@@ -83,7 +84,7 @@ def parse_args():
 class Workload:
     """Operand tables in HBM + the launch closure of one workload."""
 
-    def __init__(self, name, comm, rows, device, right_rows=0, threshold=None):
+    def __init__(self, name, comm, rows, device, right_rows=0, threshold=None, id_range=0):
         import numpy as np
         import torch
 
@@ -106,10 +107,11 @@ class Workload:
             m = right_rows or rows or 50_000
             self.threshold = 0.5 if threshold is None else threshold
             # global left corpus = world * n rows; this rank scores rows [rank*n, (rank+1)*n)
-            left = synthetic.token_sets(n, 1234 + 1000 * rank)
-            right = synthetic.token_sets(m, 5678)
+            kw = {"id_range": id_range} if id_range else {}
+            left = synthetic.token_sets(n, 1234 + 1000 * rank, **kw)
+            right = synthetic.token_sets(m, 5678, **kw)
             if rank == 0:
-                right_planted = synthetic.plant_near_duplicate_sets(left, right, 5679)
+                right_planted = synthetic.plant_near_duplicate_sets(left, right, 5679, **kw)
             else:
                 right_planted = None
             self.host = (left, right, right_planted)
@@ -600,9 +602,10 @@ def run_raw(args, comm, device, name, rows=0, right_rows=0, threshold=None, step
         capacity = 1 << 16  # ~12k hits at 1M x 1M
     if name == "term" and capacity == 1 << 13:
         capacity = 1 << 24  # ~2.6 % of the pairs reach the cache threshold 0.5
-    work = Workload(name, comm, rows, device, right_rows, threshold)
+    work = Workload(name, comm, rows, device, right_rows, threshold, getattr(args, "id_range", 0) if name in ("c2", "c4") else 0)
     # the committed profile describes the workload's default per-GPU grid (c4 divides its rows over the ranks)
-    default_shape = not rows and not right_rows and threshold is None and (name != "c4" or world == 1)
+    default_shape = (not rows and not right_rows and threshold is None and (name != "c4" or world == 1)
+                     and not getattr(args, "id_range", 0))
     # two hit buffers: the all-gather of step k overlaps the grid kernel of step k+1 (RCCL runs on
     # its own stream; the buffer is only reused after its gather has completed)
     bufs = [grid.HitBuffer(capacity, device) for _ in range(2)]

@@ -36,6 +36,23 @@ struct JacRawScalars {
   unsigned long long weak[W + 1];  // weak[|A|] bit |B|: the signature bound rarely fails for these sizes
 };
 
+// Inverted-index kernel (jaccard_raw_index.hip): slots of a wavefront's hash table; a tile holding more than 3/4
+// of that many ids is "dense" and is scored by the matrix kernel instead (launched with only_dense).
+template <int W>
+constexpr int index_slots() { return W == 16 ? 1024 : 2048; }
+
+template <int W>
+__device__ __forceinline__ bool tile_is_dense(int nrj) {  // wave-uniform
+  int total = nrj;  // wave sum of the set sizes
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) total += __shfl_xor(total, off);
+  return total > index_slots<W>() * 3 / 4;
+}
+
+template <int W>
+int launch_raw_index(const nsm_set_table* l, const nsm_set_table* r, double threshold, nsm_hit* hits, uint64_t capacity,
+                     unsigned long long* hit_count, hipStream_t stream);
+
 // Wave-uniform value -> VGPR.  On gfx950 a VALU op with an SGPR source issues at half rate
 // (4.5 vs 2.4 cycles per wave64 v_xor_b32, profiles/r01_valu_issue_rates_gfx950.txt), so an id that
 // is XORed against NB registers is first broadcast with ONE v_mov_b32.
@@ -345,6 +362,16 @@ int launch_raw(const nsm_set_table* l, const nsm_set_table* r, double threshold,
   }
   // a zero threshold (kmin == 0 everywhere) makes the bound useless; PRUNE only changes speed
   const bool prune = (flags & NSM_FLAG_PRUNE) && l->sig && r->sig;
+  if constexpr (W <= 32) {
+    // Low thresholds: the signature bound passes too often for typical set sizes (the mid-size class is "weak"),
+    // every pair would pay the position matrix.  Candidate generation by inverted index instead.
+    const bool weak_mid = (p.weak[W / 2] >> (W / 2)) & 1ull;
+    const bool use_index = threshold > 0.0 && !(flags & NSM_FLAG_NO_INDEX) &&
+                           ((flags & NSM_FLAG_INDEX) || ((flags & NSM_FLAG_PRUNE) && weak_mid));
+    if (use_index) {
+      return launch_raw_index<W>(l, r, threshold, hits, capacity, hit_count, stream);
+    }
+  }
   if (prune)
     hipLaunchKernelGGL((jaccard_raw_kernel<W, true>), grid, dim3(kBlock), 0, stream, l->ids, l->cnt,
                        l->size_start, l->sig, l->sig2, l->orig, r->ids, r->cnt, r->sig, r->sig2, r->orig, hits,

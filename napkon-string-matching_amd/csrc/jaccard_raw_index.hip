@@ -1,0 +1,223 @@
+// RAW Jaccard grid at LOW thresholds: candidate generation by a per-tile inverted index
+// (reference: napkon_string_matching/compare/score_functions.py:6-13; the API default score_threshold is 0.1,
+// types/comparable_data.py:74).
+//
+// The signature prune of jaccard_raw_kernel bounds |A n B| from above; at low thresholds one or two common ids
+// already reach kmin and the bound passes for most wavefronts, so the kernel falls back to the full W x W
+// position matrix for every pair (C2 at 0.1: 17x slower than at 0.5).  But a pair can only score above a
+// positive threshold if it SHARES an id, and that is rare when the vocabulary is large.  Here every wavefront
+// builds, once per chunk of left rows, an open-addressing hash table in LDS over the ids of its 64 right rows:
+//   id -> 64-bit mask of the lanes (right rows) that hold it.
+// Left rows are then probed 64 ids at a time -- lane = (row of the group, id slot): one coalesced load of
+// 64 / W left rows, one hash, one or two LDS reads per lane.  A row none of whose ids is in the table (the common
+// case: C2 draws 8 of 2^17 ids per row, a tile holds ~500) is finished with that; for the others the masks of
+// the found ids are added up per lane (|A n B| exactly: ids are unique per row on both sides) and compared with
+// kmin[|A| + |B|].  No signature words, no position matrix.  Data dependent by nature: with a small vocabulary
+// every id is found and the cost is one mask accumulation per left id.
+#include "jaccard_raw_impl.hpp"
+
+namespace nsm {
+
+template <int W>
+struct JacIndexScalars {
+  int32_t n_left;
+  int32_t n_right;
+  int32_t rows_per_chunk;
+  unsigned long long cap;
+  uint8_t kmin[2 * W + 4];  // indexed by |A|+|B|
+};
+
+#ifndef NSM_IDX_BLOOM_LOG
+#define NSM_IDX_BLOOM_LOG 16
+#endif
+#ifndef NSM_IDX_DEPTH
+#define NSM_IDX_DEPTH 1
+#endif
+#ifndef NSM_IDX_WAVES
+#define NSM_IDX_WAVES 1
+#endif
+// A/B on C2 at threshold 0.1 (kernel ms): bitmap 2^13 / 14 / 15 / 16 / 17 bits at 4 (2) waves per block -> 4.47 / 4.11 /
+// 2.96 / 3.48 (2.38) / (3.06); waves per block 4 / 2 / 1 at 2^16 -> 3.48 / 2.38 / 2.05; prefetch depth 1 / 2 / 4 -> 3.93 / 4.11 / 4.31
+constexpr int32_t kEmptyKey = -3;  // ids are >= 0, padding is -1 (left) / -2 (right)
+
+template <int W>
+__global__ __launch_bounds__(kBlock) void jaccard_raw_index_kernel(
+    const int32_t* __restrict__ lids, const int32_t* __restrict__ lcnt, const int32_t* __restrict__ lorig,
+    const int32_t* __restrict__ rids, const int32_t* __restrict__ rcnt, const int32_t* __restrict__ rorig,
+    nsm_hit* __restrict__ hits, unsigned long long* __restrict__ count, const JacIndexScalars<W> p) {
+  constexpr int T = index_slots<W>();
+  constexpr int kLog = W == 16 ? 10 : 11;
+  constexpr int kRowsPerGroup = kWave / W;  // left rows probed at once (W = 16: 4, W = 32: 2)
+  extern __shared__ __attribute__((aligned(16))) unsigned long long s_idx[];
+  // per wave: [T] u64 masks | [T] i32 keys | [kBloomWords] u32 presence bitmap; then kmin
+  constexpr int kBloomLog = NSM_IDX_BLOOM_LOG;  // presence bitmap: 2^16 bits = 8 KB, < 1 % of absent ids pass at 512 ids per tile
+  constexpr int kBloomWords = (1 << kBloomLog) / 32;
+  constexpr int kWaveWords = T + T / 2 + kBloomWords / 2;  // u64 units
+  const int waves = blockDim.x >> 6;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  unsigned long long* tmask = s_idx + static_cast<size_t>(wave) * kWaveWords;
+  int32_t* tkey = reinterpret_cast<int32_t*>(tmask + T);
+  uint32_t* bloom = reinterpret_cast<uint32_t*>(tkey + T);
+  uint8_t* s_kmin = reinterpret_cast<uint8_t*>(s_idx + static_cast<size_t>(waves) * kWaveWords);
+  for (int t = threadIdx.x; t < 2 * W + 4; t += blockDim.x) s_kmin[t] = p.kmin[t];
+  __syncthreads();
+
+  const int tile = blockIdx.x * waves + wave;
+  if (tile * kWave >= p.n_right) return;  // whole wave
+  const int j = tile * kWave + lane;
+  const bool valid = j < p.n_right;
+  const int jc = valid ? j : p.n_right - 1;
+  const int nrj = valid ? rcnt[jc] : 0;
+  // a tile with more ids than 3/4 of the table is indexed in two halves (lanes 0..31, then 32..63): the masks of a
+  // pass only carry its lanes, so the other lanes count 0 common ids and cannot hit
+  const int n_pass = tile_is_dense<W>(nrj) ? 2 : 1;
+  const int jorig = rorig[jc];
+  for (int pass = 0; pass < n_pass; ++pass) {
+  const bool in_pass = n_pass == 1 || (lane >> 5) == pass;
+
+  // ---- build: every lane inserts its row's ids (hash table + presence bitmap)
+  for (int c = lane; c < T; c += kWave) {
+    tmask[c] = 0ull;
+    tkey[c] = kEmptyKey;
+  }
+  for (int c = lane; c < kBloomWords; c += kWave) bloom[c] = 0u;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  {
+    const int32_t* rrow = rids + static_cast<size_t>(jc) * W;
+    for (int q = 0; q < (in_pass ? nrj : 0); ++q) {
+      const int32_t id = rrow[q];
+      const uint32_t hh = static_cast<uint32_t>(id) * 0x9E3779B1u;
+      uint32_t h = hh >> (32 - kLog);
+      for (int tries = 0; tries < T; ++tries) {
+        const int32_t prev = atomicCAS(&tkey[h], kEmptyKey, id);
+        if (prev == kEmptyKey || prev == id) break;
+        h = (h + 1) & (T - 1);
+      }
+      atomicOr(&tmask[h], 1ull << lane);
+      const uint32_t bit = hh >> (32 - kBloomLog);
+      atomicOr(&bloom[bit >> 5], 1u << (bit & 31u));
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  const int i0 = blockIdx.y * p.rows_per_chunk;
+  const int i1 = min(p.n_left, i0 + p.rows_per_chunk);
+  const int sub = lane / W;  // which row of the group this lane probes for
+  // the next group's ids (and its rows' sizes) are requested while the current group is probed
+  auto load_group = [&](int ig, int32_t& id, int32_t& nl) {
+    const int irow = ig + sub;
+    const bool on = irow < i1;
+    id = on ? lids[static_cast<size_t>(irow) * W + (lane & (W - 1))] : -1;
+    nl = on ? lcnt[irow] : 0;
+  };
+  // software pipeline, kDepth groups deep: a group's ids are requested kDepth iterations before they are probed
+  // (one iteration is ~300 cycles of work, a global load ~1000: with one group in flight the wave waited for it)
+  constexpr int kDepth = NSM_IDX_DEPTH;
+  int32_t id_q[kDepth], nl_q[kDepth];
+#pragma unroll
+  for (int d = 0; d < kDepth; ++d) load_group(i0 + d * kRowsPerGroup, id_q[d], nl_q[d]);
+  for (int ig0 = i0; ig0 < i1; ig0 += kDepth * kRowsPerGroup) {
+#pragma unroll
+   for (int d = 0; d < kDepth; ++d) {
+    const int ig = ig0 + d * kRowsPerGroup;
+    if (ig >= i1) break;
+    const int32_t id = id_q[d], nlv = nl_q[d];
+    load_group(ig + kDepth * kRowsPerGroup, id_q[d], nl_q[d]);
+    // ---- probe: lane = (row ig + sub, id slot lane % W); the bitmap answers "not in this tile" for ~98 %
+    bool found = false;
+    unsigned long long m = 0ull;
+    const uint32_t hh = static_cast<uint32_t>(id) * 0x9E3779B1u;
+    const uint32_t bit = hh >> (32 - kBloomLog);
+    if (id >= 0 && ((bloom[bit >> 5] >> (bit & 31u)) & 1u)) {
+      uint32_t h = hh >> (32 - kLog);
+      for (int tries = 0; tries < T; ++tries) {
+        const int32_t k = tkey[h];
+        if (k == id) {
+          found = true;
+          m = tmask[h];
+          break;
+        }
+        if (k == kEmptyKey) break;
+        h = (h + 1) & (T - 1);
+      }
+    }
+    const unsigned long long who = __ballot(found);
+    if (who == 0ull) continue;  // none of the group's ids occurs in the tile: no pair shares an id
+    const uint32_t m_lo = static_cast<uint32_t>(m), m_hi = static_cast<uint32_t>(m >> 32);
+    // ---- the rows of the group that found something: |A n B| per lane = sum of the found ids' masks
+    for (int rr = 0; rr < kRowsPerGroup; ++rr) {
+      unsigned long long mine = (who >> (rr * W)) & ((1ull << (W % 64)) - 1ull);
+      if (mine == 0ull) continue;
+      const int i = ig + rr;
+      int k = 0;
+      while (mine) {
+        const int q = __builtin_ctzll(mine) + rr * W;
+        mine &= mine - 1;
+        // (readlane returns a signed int: without the casts the low half sign-extends into the high one)
+        const unsigned long long mq =
+            (static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(m_hi), q))) << 32) |
+            static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(m_lo), q)));
+        k += static_cast<int>((mq >> lane) & 1ull);
+      }
+      const int nl = __builtin_amdgcn_readlane(nlv, rr * W);
+      const int need = valid ? s_kmin[nl + nrj] : kNever;
+      const bool hit = k >= need;
+      if (__any(hit))
+        emit_hits_wave(hits, p.cap, count, hit, static_cast<double>(k) / static_cast<double>(nl + nrj - k), lorig[i], jorig);
+    }
+   }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the table is rebuilt by the next pass
+  __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// kmin as in jaccard_raw_impl.hpp (fill_kmin): least k with double(k)/double(s-k) >= threshold
+template <int W>
+static void index_fill_kmin(uint8_t* kmin, double threshold) {
+  for (int s = 0; s < 2 * W + 4; ++s) {
+    kmin[s] = kNever;
+    if (s == 0 || s > 2 * W) continue;
+    for (int k = 0; 2 * k <= s; ++k) {
+      const volatile double q = static_cast<double>(k) / static_cast<double>(s - k);
+      if (q >= threshold) {
+        kmin[s] = static_cast<uint8_t>(k);
+        break;
+      }
+    }
+  }
+}
+
+template <int W>
+int launch_raw_index(const nsm_set_table* l, const nsm_set_table* r, double threshold, nsm_hit* hits, uint64_t capacity,
+                     unsigned long long* hit_count, hipStream_t stream) {
+  JacIndexScalars<W> p;
+  p.n_left = l->n; p.n_right = r->n; p.cap = capacity;
+  index_fill_kmin<W>(p.kmin, threshold);
+  constexpr int T = index_slots<W>();
+  const int waves = W == 16 ? NSM_IDX_WAVES : 2;  // 12 / 24 KB of table per wave
+  const int n_tiles = (r->n + kWave - 1) / kWave;
+  // the table is rebuilt per (tile, chunk): long chunks, but enough blocks to fill the chip
+  long long rows = 2048;
+  while (rows > 256 && static_cast<long long>((n_tiles + waves - 1) / waves) * ((l->n + rows - 1) / rows) < 4096) rows /= 2;
+  p.rows_per_chunk = static_cast<int>(rows);
+  dim3 grid((n_tiles + waves - 1) / waves, (l->n + p.rows_per_chunk - 1) / p.rows_per_chunk);
+  if (grid.y > 65535) {
+    p.rows_per_chunk = (l->n + 65534) / 65535;
+    grid.y = (l->n + p.rows_per_chunk - 1) / p.rows_per_chunk;
+  }
+  const size_t lds = static_cast<size_t>(waves) * (T + T / 2 + (1 << NSM_IDX_BLOOM_LOG) / 64) * 8 + 2 * W + 4;  // + the presence bitmap per wave
+  hipLaunchKernelGGL((jaccard_raw_index_kernel<W>), grid, dim3(waves * kWave), lds, stream, l->ids, l->cnt, l->orig, r->ids,
+                     r->cnt, r->orig, hits, hit_count, p);
+  return hip_status(hipGetLastError(), "jaccard_raw_index_kernel launch");
+}
+
+template int launch_raw_index<16>(const nsm_set_table*, const nsm_set_table*, double, nsm_hit*, uint64_t, unsigned long long*,
+                                  hipStream_t);
+template int launch_raw_index<32>(const nsm_set_table*, const nsm_set_table*, double, nsm_hit*, uint64_t, unsigned long long*,
+                                  hipStream_t);
+
+}  // namespace nsm

@@ -100,9 +100,11 @@ def run_grid(launch: Callable[[HitBuffer, int], int], device, capacity: Optional
 
 # ------------------------------------------------------------------------------- RAW grids
 def jaccard_raw_grid(
-    left: SetTable, right: SetTable, threshold: float, prune: bool = True, capacity: Optional[int] = None
+    left: SetTable, right: SetTable, threshold: float, prune: bool = True, capacity: Optional[int] = None,
+    index: Optional[bool] = None,
 ) -> Hits:
-    """``intersection_vs_union`` on one set per item, all N x M pairs, hits ``>= threshold``."""
+    """``intersection_vs_union`` on one set per item, all N x M pairs, hits ``>= threshold``.
+    ``index``: None = the library decides (inverted-index candidates at low thresholds), True / False = force."""
     if left.side != "left" or right.side != "right":
         raise ValueError("tables must be encoded with side='left' and side='right' (distinct padding)")
     if left.has_empty and right.has_empty:
@@ -110,7 +112,7 @@ def jaccard_raw_grid(
         raise ZeroDivisionError("division by zero")
     lib = _lib.load()
     ls, rs = left.struct(), right.struct()
-    flags = _lib.FLAG_PRUNE if prune else 0
+    flags = (_lib.FLAG_PRUNE if prune else 0) | (0 if index is None else (_lib.FLAG_INDEX if index else _lib.FLAG_NO_INDEX))
 
     def launch(buf: HitBuffer, stream: int) -> int:
         return lib.nsm_jaccard_raw_grid(

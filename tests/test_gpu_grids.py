@@ -56,6 +56,49 @@ def test_jaccard_raw_random(dev, width, kmax, vocab, prune):
         _same_hits(got, want)
 
 
+@pytest.mark.parametrize("width,kmax,vocab,n_left,n_right", [
+    (16, 16, 60, 333, 517),         # tiny vocabulary: every pair is a candidate, the early tiles are dense
+    (16, 10, 5000, 2100, 1700),     # sparse: most probes miss
+    (16, 16, 100000, 900, 2500),    # all rows full: every tile is dense (the matrix kernel takes them)
+    (32, 30, 700, 700, 900),
+    (32, 12, 90, 300, 400),
+])
+def test_jaccard_raw_inverted_index(dev, width, kmax, vocab, n_left, n_right):
+    """Candidate generation by inverted index (low thresholds) == the matrix kernel == the oracle, forced on
+    and chosen by the library; partial last tile, empty sets, dense and sparse tiles."""
+    from napkon_string_matching_amd import grid, tables
+    from oracle import native
+
+    rng = random.Random(width * 77 + vocab)
+    left = _rand_padded(rng, n_left, width, vocab, kmax, allow_empty=False)  # (empty x empty is the host's ZeroDivisionError)
+    right = _rand_padded(rng, n_right, width, vocab, kmax, allow_empty=True)
+    if vocab == 100000:
+        for row in right:
+            row[:] = rng.sample(range(vocab), width)
+    lt = tables.SetTable.from_padded(left, "left", dev, width=width)
+    rt = tables.SetTable.from_padded(right, "right", dev, width=width)
+    for thr in (0.01, 0.1, 0.25, 0.5, 1.0):
+        want = native.jaccard_raw(native.csr_from_padded(left), native.csr_from_padded(right), thr, cap=1 << 20)
+        forced = grid.jaccard_raw_grid(lt, rt, thr, index=True, capacity=1 << 12)
+        _same_hits(forced, want)
+        _same_hits(grid.jaccard_raw_grid(lt, rt, thr, capacity=1 << 12), want)               # the library's choice
+        _same_hits(grid.jaccard_raw_grid(lt, rt, thr, index=False, capacity=1 << 12), want)  # never the index
+
+
+def test_jaccard_raw_c2_shaped_low_threshold(dev):
+    """configs[1]'s generator at the API's default threshold 0.1 (types/comparable_data.py:74), 20k x 20k: the
+    index kernel against the exhaustive matrix kernel, and the collision-crafted ids of the signature test."""
+    from napkon_string_matching_amd import grid, synthetic, tables
+
+    left, right = synthetic.c2_corpus(20000, 20000)
+    lt = tables.SetTable.from_padded(left, "left", dev)
+    rt = tables.SetTable.from_padded(right, "right", dev)
+    exhaustive = grid.jaccard_raw_grid(lt, rt, 0.1, prune=False, index=False).as_tuples()
+    assert len(exhaustive) > 1000
+    assert grid.jaccard_raw_grid(lt, rt, 0.1).as_tuples() == exhaustive
+    assert grid.jaccard_raw_grid(lt, rt, 0.1, index=True).as_tuples() == exhaustive
+
+
 def test_jaccard_raw_c2_shaped(dev):
     """BASELINE configs[1] generator at 6000 x 5000 (the oracle finishes in seconds)."""
     from napkon_string_matching_amd import grid, synthetic, tables
