@@ -242,8 +242,11 @@ __device__ __forceinline__ void wave_rows(const int32_t* __restrict__ lids,
   }
 }
 
+#ifndef NSM_JAC_OCC
+#define NSM_JAC_OCC
+#endif
 template <int W, bool PRUNE>
-__global__ __launch_bounds__(kBlock) void jaccard_raw_kernel(
+__global__ __launch_bounds__(kBlock) NSM_JAC_OCC void jaccard_raw_kernel(
     const int32_t* __restrict__ lids, const int32_t* __restrict__ lcnt,
     const int32_t* __restrict__ lstart, const uint64_t* __restrict__ lsig,
     const uint64_t* __restrict__ lsig2,
@@ -361,7 +364,11 @@ int launch_raw(const nsm_set_table* l, const nsm_set_table* r, double threshold,
     grid.y = (l->n + p.rows_per_chunk - 1) / p.rows_per_chunk;
   }
   // a zero threshold (kmin == 0 everywhere) makes the bound useless; PRUNE only changes speed
-  const bool prune = (flags & NSM_FLAG_PRUNE) && l->sig && r->sig;
+  // W = 64: the pruned instantiation needs > 256 VGPRs (416 B of scratch, -Rpass-analysis=kernel-resource-usage) and a
+  // 58-bit signature of 33..64 ids is saturated anyway (every size class is "weak": the prune switches itself off).
+  // Measured on 20k x 20k sets of ~44 ids at 0.5: pruned 39.1 ms, exhaustive 38.2 ms (tools/bench_w64.py) -- the
+  // spill-free exhaustive instantiation (142 VGPRs) runs wide sets.
+  const bool prune = (flags & NSM_FLAG_PRUNE) && l->sig && r->sig && W < 64;
   if constexpr (W <= 32) {
     // Low thresholds: the signature bound passes too often for typical set sizes (the mid-size class is "weak"),
     // every pair would pay the position matrix.  Candidate generation by inverted index instead.
