@@ -377,7 +377,7 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
     q.park_max = NSM_PARK_MAX;
     q.rows_per_chunk = p.rows_per_chunk;
     const size_t tbl_bytes = static_cast<size_t>(q.pm_stride) * pm_words * 8;
-    const size_t fixed_wave = (K > 1 ? 16 * K * kWave * 4 : 0) + batch * kWave * 2 +
+    const size_t fixed_wave = (K > 1 ? 16 * K * kWave * 4 + batch * kWave * 8 : 0) + batch * kWave * 2 +
                               batch * 3 * kHeadDwords * 4 + batch * kWave * K;
     const int sub = park_sub(K);
     const size_t park_bytes = static_cast<size_t>(q.park_slots) * sub * 16 + 66 * 16 + 8 + 4 * sub * 4;
@@ -397,7 +397,10 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
     if (left->seg) {
       // partitioned: y = slices of every category's row range (all blocks have work); ~256 rows per slice when
       // the rows spread over ~32 categories, enough blocks to fill the chip when they do not
-      long long slices = (left->n + 8191) / 8192;
+#ifndef NSM_PARK_SLICE_ROWS
+#define NSM_PARK_SLICE_ROWS 8192
+#endif
+      long long slices = (left->n + NSM_PARK_SLICE_ROWS - 1) / NSM_PARK_SLICE_ROWS;
       if (slices < 1) slices = 1;
       if (slices > 1024) slices = 1024;
       while (slices < 64 && static_cast<long long>(pgrid.x) * slices < 4096) slices *= 2;

@@ -136,12 +136,13 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
 
   const int tbl_entries = p.pm_stride * kPmWords<K>;
   const size_t wave_bytes = static_cast<size_t>(p.fin_rows) * tbl_entries * 8 + (K > 1 ? 16 * K * kWave * 4 : 0) +
-                            kBatch * kWave * 2 + kBatch * 3 * kHeadDwords * 4 + kBatch * kRow;
+                            kBatch * kWave * 2 + (K > 1 ? kBatch * kWave * 8 : 0) + kBatch * 3 * kHeadDwords * 4 + kBatch * kRow;
   unsigned char* wbase = reinterpret_cast<unsigned char*>(s_mem) + wave * wave_bytes;
   unsigned long long* pm = reinterpret_cast<unsigned long long*>(wbase);
   uint32_t* wtext = reinterpret_cast<uint32_t*>(pm + static_cast<size_t>(p.fin_rows) * tbl_entries);
   uint16_t* need = reinterpret_cast<uint16_t*>(wtext + (K > 1 ? 16 * K * kWave : 0));
-  uint32_t* head = reinterpret_cast<uint32_t*>(need + kBatch * kWave);
+  double* sc = reinterpret_cast<double*>(need + kBatch * kWave);  // (K > 1) running scores of the rows that go on wave-wide
+  uint32_t* head = reinterpret_cast<uint32_t*>(sc + (K > 1 ? kBatch * kWave : 0));
   uint8_t* lstr = reinterpret_cast<uint8_t*>(head + kBatch * 3 * kHeadDwords);
   unsigned char* bbase = reinterpret_cast<unsigned char*>(s_mem) + waves * wave_bytes;
   const int park_total = p.park_slots * kSub;
@@ -662,12 +663,118 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
       after_lcs(r, la, lcs);
     }
     if (over) {
-      text_row = -1;  // the text image's registers are free for the dense steps
-      for (uint32_t rows = over; rows;) {
-        const int r = __builtin_ctz(rows);
-        rows &= rows - 1;
-        const int lcs1 = need[r * kWave + lane];
-        dense_steps(ib, nrows, lcs1 != kDeadNeed, r, jc, 2, __longlong_as_double(static_cast<long long>(lcs1)), true, reg);
+      if constexpr (K == 1) {
+        text_row = -1;  // the text image's registers are free for the dense steps
+        for (uint32_t rows = over; rows;) {
+          const int r = __builtin_ctz(rows);
+          rows &= rows - 1;
+          const int lcs1 = need[r * kWave + lane];
+          dense_steps(ib, nrows, lcs1 != kDeadNeed, r, jc, 2, __longlong_as_double(static_cast<long long>(lcs1)), true, reg);
+        }
+      } else {
+        // Multi-word strings at low thresholds keep most lanes alive after step 1 (Term-like items at 0.5: 61 %):
+        // those rows go on wave-wide and STEP-MAJOR -- per step the lane's right level string is staged once for
+        // all of them, the left level strings come from one staging pass, the left histograms of steps <= 3 from
+        // the heads -- until few enough lanes are left to park.  (Row-major dense steps re-staged the 256-byte
+        // text and chased the rows' metadata through global memory per row and step: 163 vs 140 ms.)
+        const uint32_t over0 = over;
+        int ll_max = 0;
+        for (uint32_t rows = over; rows;) {
+          const int r = __builtin_ctz(rows);
+          rows &= rows - 1;
+          const int lcs1 = need[r * kWave + lane];
+          const int la1 = wave_first(static_cast<int>(head[r * 3 * kHeadDwords + NB]));
+          sc[r * kWave + lane] = lcs1 != kDeadNeed ? ratio_of(la1, lb, lcs1) * 0.5 : __builtin_nan("");
+          ll_max = max(ll_max, wave_first(static_cast<int>(head[r * 3 * kHeadDwords + NB + 2])));
+        }
+        const int steps_max = max(ll_max, lr_max);
+        double factor = 0.5;
+        for (int s = 2; s <= steps_max && over; ++s) {
+          factor *= 0.5;
+          stage_strings(ib, over, s);
+          const int rrow_s = rrow0 + max(0, min(s, lr - 1));
+          if (__any(rrow_s != text_row)) {
+            text_row = rrow_s;
+            wide_store_text<K>(wtext, rcodes + static_cast<size_t>(rrow_s) * kRow, lane);
+            lb = rlen[rrow_s];
+          }
+          const int nch = wave_max_i32(valid ? lb : 0);
+          // the lane's histogram of the NEXT step's level bounds what is still to come: once per step
+          const int rrow_n = rrow0 + max(0, min(s + 1, lr - 1));
+          const int lb_n = rlen[rrow_n];
+          uint32_t hbn[8];
+          if (use_hist) load_hist<8>(rhist, rrow_n, hbn);
+          for (uint32_t rows = over; rows;) {
+            const int r = __builtin_ctz(rows);
+            rows &= rows - 1;
+            const uint32_t* rec = head + r * 3 * kHeadDwords;
+            const int ll = wave_first(static_cast<int>(rec[NB + 2]));
+            const int lf = wave_first(static_cast<int>(rec[NB + 3]));
+            const int S = max(ll, lr);
+            double score = sc[r * kWave + lane];
+            const bool run = (score == score) && s <= S;  // NaN = dropped or parked
+            if (!__any(run)) {  // finished lanes keep their final scores in sc
+              over &= ~(1u << r);
+              continue;
+            }
+            int la = s <= 3 ? static_cast<int>(rec[(s - 1) * kHeadDwords + NB]) : llen[lf + max(0, min(s, ll - 1))];
+            la = wave_first(la);
+            build_pm_staged(r, la);
+            const int lcs = wide_lcs<K>(pm, wtext, nch, lane, la);
+            if (run) score += ratio_of(la, lb, lcs) * factor;
+            float rest = 0.0f;
+            if (s < S) {
+              const int t = s + 1;
+              float ub = 1.0f;
+              if (use_hist) {
+                uint32_t hl[8];
+                int la_n;
+                if (t <= 3) {
+                  la_n = static_cast<int>(rec[(t - 1) * kHeadDwords + NB]);
+#pragma unroll
+                  for (int q = 0; q < 8; ++q) hl[q] = rec[(t - 1) * kHeadDwords + q];
+                } else {
+                  const int lrow_n = lf + max(0, min(t, ll - 1));
+                  la_n = llen[lrow_n];
+                  load_hist<8>(lhist, lrow_n, hl);
+                }
+                ub = hist_ratio_ub(hist_l1<8>(hl, hbn), la_n, lb_n);
+              }
+              rest = rest_bound(s, S, ub);
+            }
+            const bool alive = run && (score + static_cast<double>(rest) + 1e-6 >= p.threshold);
+            if (run && !alive) score = __builtin_nan("");
+            const bool pending = alive && s < S;
+            const unsigned long long who = __ballot(pending);
+            const int n = __popcll(who);
+            if (n > 0 && n <= p.park_max) {
+              const int have = reserve(reg, n);
+              if (have >= 0) {
+                if (pending) {
+                  const int slot = (reg % kSub) * p.park_slots + have +
+                                   __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(who >> 32),
+                                                             __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(who), 0u));
+                  park_score[slot] = score;
+                  park_j[slot] = jc;
+                  park_meta[slot] = r | ((s + 1) << 8);
+                  score = __builtin_nan("");  // the dense pass owns the pair now
+                }
+                sc[r * kWave + lane] = score;
+                over &= ~(1u << r);
+                continue;
+              }
+            }
+            sc[r * kWave + lane] = score;
+            if (n == 0) over &= ~(1u << r);
+          }
+        }
+        for (uint32_t rows = over0; rows;) {  // pairs that finished in the wave-wide steps
+          const int r = __builtin_ctz(rows);
+          rows &= rows - 1;
+          const double score = sc[r * kWave + lane];
+          emit_hits_wave(hits, p.cap, count, score >= p.threshold, score, lorig[ib + r], jorig);
+        }
+        text_row = -1;  // step 1 of the next batch reads another level
       }
     }
   };
