@@ -677,6 +677,9 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
         // all of them, the left level strings come from one staging pass, the left histograms of steps <= 3 from
         // the heads -- until few enough lanes are left to park.  (Row-major dense steps re-staged the 256-byte
         // text and chased the rows' metadata through global memory per row and step: 163 vs 140 ms.)
+#ifdef NSM_X_NOCONT
+        over = 0;
+#endif
         const uint32_t over0 = over;
         int ll_max = 0;
         for (uint32_t rows = over; rows;) {

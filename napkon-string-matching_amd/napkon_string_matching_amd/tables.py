@@ -674,7 +674,7 @@ class LevelItems:
         )
 
 
-def _level_items_device(first, nlev, cat, offset, mode, do_partition, device) -> "LevelItems":
+def _level_items_device(first, nlev, cat, orig, mode, do_partition, device) -> "LevelItems":
     """``LevelItems`` built on the GPU by ``nsm_build_level_items`` (``cat`` already carries bit 63 for the
     empty items when the partition turned "both empty" into a category)."""
     lib = _lib.load()
@@ -689,7 +689,7 @@ def _level_items_device(first, nlev, cat, offset, mode, do_partition, device) ->
                     seg_start=new(65, torch.int32) if do_partition else None, category_mode=mode)
     d_first, d_nlev = _dev(first, dev), _dev(nlev, dev)
     d_cat = None if cat is None else _dev(np.asarray(cat, dtype=np.uint64).view(np.int64), dev)
-    d_orig = _dev((np.arange(n, dtype=np.int32) + offset).astype(np.int32), dev) if offset else None
+    d_orig = _dev(np.asarray(orig, dtype=np.int32), dev)  # the caller's item ids (the rows arrive pre-ordered)
     st = li.struct()
     # the mode the builder sees is the one AFTER the rewrite: the caller already folded "both empty" into bit 63
     _lib.check(lib.nsm_build_level_items(_ptr(d_first), _ptr(d_nlev), _ptr(d_cat), _ptr(d_orig), n,
@@ -768,29 +768,40 @@ def encode_level_codes(
         if len(nlev) and int(nlev.max()) > MAX_LEVELS:
             raise NotImplementedError(f"an item has {int(nlev.max())} levels > {MAX_LEVELS}")
         table = StrTable.from_codes(codes, lengths, alphabet, device, sort=False)
+        # Items are pre-ordered by (depth, length of the step-1 level string), both descending: the builder's sort
+        # (category, depth) is stable, so inside a depth class a wavefront's 64 items have step-1 strings of similar
+        # length -- the LCS loops run to the wave's LONGEST text (Term-like items: mean 59, wave maximum ~110
+        # code units when unordered).
+        lengths = np.asarray(lengths, dtype=np.int32)
+        len1 = np.where(nlev > 0, lengths[np.minimum(first + np.minimum(1, np.maximum(nlev, 1) - 1), max(len(lengths) - 1, 0))], 0) \
+            if len(lengths) else np.zeros(len(first), dtype=np.int32)
+        pre = np.lexsort((-len1, -nlev)).astype(np.int32)
         if _on_gpu(device):
-            return _level_items_device(first, nlev, cat, offset, mode, do_partition, device), table
+            return _level_items_device(first[pre], nlev[pre], None if cat is None else cat[pre], pre + offset, mode,
+                                       do_partition, device), table
+        first_p, nlev_p, cat_p = first[pre], nlev[pre], (None if cat is None else cat[pre])
         item = np.arange(len(first), dtype=np.int32)
         seg = seg_start = None
         if do_partition:
             rows, segs = [], []
             for c in range(64):
-                has = np.flatnonzero((cat >> np.uint64(c)) & np.uint64(1))
+                has = np.flatnonzero((cat_p >> np.uint64(c)) & np.uint64(1))
                 rows.append(has.astype(np.int32))
                 segs.append(np.full(len(has), c, dtype=np.int32))
             item = np.concatenate(rows) if rows else item[:0]
             seg = np.concatenate(segs) if segs else np.zeros(0, np.int32)
-            # inside a category: deeper items first, so a wavefront's items have similar depth
-            order = np.lexsort((-nlev[item], seg))
+            # inside a category: deeper items first, so a wavefront's items have similar depth (stable: the
+            # pre-order survives inside a depth class)
+            order = np.lexsort((-nlev_p[item], seg))
             item, seg = item[order], seg[order]
             seg_start = np.zeros(65, dtype=np.int32)
             seg_start[1:] = np.cumsum(np.bincount(seg, minlength=64)[:64])
         else:
-            item = item[np.argsort(-nlev, kind="stable")]
+            item = item[np.argsort(-nlev_p, kind="stable")]
         li = LevelItems(
-            first=_dev(first[item], device), nlev=_dev(nlev[item], device),
-            orig=_dev((item + offset).astype(np.int32), device),
-            cat=None if cat is None else _dev(cat[item], device), n=len(item),
+            first=_dev(first_p[item], device), nlev=_dev(nlev_p[item], device),
+            orig=_dev((pre[item] + offset).astype(np.int32), device),
+            cat=None if cat_p is None else _dev(cat_p[item], device), n=len(item),
             seg=None if seg is None else _dev(seg, device),
             seg_start=None if seg_start is None else _dev(seg_start, device), category_mode=mode,
         )
