@@ -373,7 +373,10 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
 #ifndef NSM_PARK_MAX
 #define NSM_PARK_MAX 24
 #endif
-    q.park_slots = 128;  // per region (park_sub(K) regions); 64 overflow on Term-like strings (140 -> 157 ms)
+#ifndef NSM_PARK_SLOTS_WIDE
+#define NSM_PARK_SLOTS_WIDE 96
+#endif
+    q.park_slots = K >= 4 ? NSM_PARK_SLOTS_WIDE : 128;  // per region (park_sub(K) regions); 64 overflow on Term-like strings (140 -> 157 ms)
     q.park_max = NSM_PARK_MAX;
     q.rows_per_chunk = p.rows_per_chunk;
     const size_t tbl_bytes = static_cast<size_t>(q.pm_stride) * pm_words * 8;
@@ -382,7 +385,10 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
     const int sub = park_sub(K);
     const size_t park_bytes = static_cast<size_t>(q.park_slots) * sub * 16 + 66 * 16 + 8 + 4 * sub * 4;
     // one-word text images hold 16-bit LDS addresses: the block stays under 64 KiB (and so do the others)
-    const size_t budget = 60 * 1024;
+#ifndef NSM_PARK_LDS_BUDGET_WIDE
+#define NSM_PARK_LDS_BUDGET_WIDE (53 * 1024)  // three blocks of two waves per CU (60 KB: two blocks; term 113 -> 93 ms)
+#endif
+    const size_t budget = K >= 4 ? NSM_PARK_LDS_BUDGET_WIDE : 60 * 1024;
     int pw = 4;  // waves (= right tiles) per block: as many as fit with one mask table each ...
     while (pw > 1 && pw * (tbl_bytes + fixed_wave) + park_bytes > budget) pw >>= 1;
     q.fin_rows = batch;  // ... then as many tables for the dense pass as fit
