@@ -276,8 +276,8 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
   };
 
   // match masks of the staged string of row r (la code units) into table 0
-  auto build_pm_staged = [&](int r, int la) __attribute__((always_inline)) {
-    for (int c = lane; c < tbl_entries; c += kWave) pm[c] = 0ull;
+  auto build_pm_table = [&](unsigned long long* tb, int r, int la) __attribute__((always_inline)) {
+    for (int c = lane; c < tbl_entries; c += kWave) tb[c] = 0ull;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -285,12 +285,13 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
       const int pos = lane + kWave * k;
       if (pos < la) {
         const unsigned c = lstr[r * kRow + pos];
-        atomicOr(&pm[c * kPmWords<K> + k], 1ull << lane);
+        atomicOr(&tb[c * kPmWords<K> + k], 1ull << lane);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
   };
+  auto build_pm_staged = [&](int r, int la) __attribute__((always_inline)) { build_pm_table(pm, r, la); };
 
   // ---- remaining steps of up to 64 pairs, lane = one pair (left row ib + r of the batch, right item row jr,
   // next step s0, score so far -- or, `packed`, the step-1 LCS in the score's bits).  Used for the parked
@@ -610,6 +611,21 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
           continue;
         }
       }
+      if constexpr (K > 1) {
+        // two left rows per pass (multi-word strings): tables 0 and 1 of the wave, one text read for both
+        const int r2 = rows ? __builtin_ctz(rows) : -1;
+        const int la2 = r2 >= 0 ? wave_first(static_cast<int>(head[r2 * 3 * kHeadDwords + NB])) : 0;
+        if (r2 >= 0 && p.fin_rows >= 2 && max(la, la2) <= 2 * kWave) {
+          rows &= rows - 1;
+          build_pm_table(pm, r, la);
+          build_pm_table(pm + tbl_entries, r2, la2);
+          int lcs_a, lcs_b;
+          wide_lcs2<K>(pm, pm + tbl_entries, wtext, nchars, lane, max(la, la2), lcs_a, lcs_b);
+          after_lcs(r, la, lcs_a);
+          after_lcs(r2, la2, lcs_b);
+          continue;
+        }
+      }
 #ifndef NSM_X_NOPM
       build_pm_staged(r, la);
 #endif
@@ -707,23 +723,27 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
           const int lb_n = rlen[rrow_n];
           uint32_t hbn[8];
           if (use_hist) load_hist<8>(rhist, rrow_n, hbn);
-          for (uint32_t rows = over; rows;) {
-            const int r = __builtin_ctz(rows);
-            rows &= rows - 1;
+          // the left level of step s of row r: its length (heads for s <= 3)
+          auto level_len = [&](int r) -> int {
+            const uint32_t* rec = head + r * 3 * kHeadDwords;
+            const int ll = wave_first(static_cast<int>(rec[NB + 2]));
+            const int lf = wave_first(static_cast<int>(rec[NB + 3]));
+            const int la = s <= 3 ? static_cast<int>(rec[(s - 1) * kHeadDwords + NB]) : llen[lf + max(0, min(s, ll - 1))];
+            return wave_first(la);
+          };
+          auto still_running = [&](int r) -> bool {  // wave-uniform: some lane of row r still scores step s
+            const int ll = wave_first(static_cast<int>(head[r * 3 * kHeadDwords + NB + 2]));
+            const double score = sc[r * kWave + lane];
+            return __any((score == score) && s <= max(ll, lr));
+          };
+          // what follows the LCS of (row r, step s): score, bound on the rest, park or go on
+          auto after_step = [&](int r, int la, int lcs) __attribute__((always_inline)) {
             const uint32_t* rec = head + r * 3 * kHeadDwords;
             const int ll = wave_first(static_cast<int>(rec[NB + 2]));
             const int lf = wave_first(static_cast<int>(rec[NB + 3]));
             const int S = max(ll, lr);
             double score = sc[r * kWave + lane];
             const bool run = (score == score) && s <= S;  // NaN = dropped or parked
-            if (!__any(run)) {  // finished lanes keep their final scores in sc
-              over &= ~(1u << r);
-              continue;
-            }
-            int la = s <= 3 ? static_cast<int>(rec[(s - 1) * kHeadDwords + NB]) : llen[lf + max(0, min(s, ll - 1))];
-            la = wave_first(la);
-            build_pm_staged(r, la);
-            const int lcs = wide_lcs<K>(pm, wtext, nch, lane, la);
             if (run) score += ratio_of(la, lb, lcs) * factor;
             float rest = 0.0f;
             if (s < S) {
@@ -764,11 +784,37 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
                 }
                 sc[r * kWave + lane] = score;
                 over &= ~(1u << r);
-                continue;
+                return;
               }
             }
             sc[r * kWave + lane] = score;
             if (n == 0) over &= ~(1u << r);
+          };
+          for (uint32_t rows = over; rows;) {
+            const int r = __builtin_ctz(rows);
+            rows &= rows - 1;
+            if (!still_running(r)) {  // finished lanes keep their final scores in sc
+              over &= ~(1u << r);
+              continue;
+            }
+            const int la = level_len(r);
+            // two rows per pass when the next row is still running too (tables 0 and 1, one text read for both)
+            const int r2 = rows ? __builtin_ctz(rows) : -1;
+            if (r2 >= 0 && p.fin_rows >= 2 && still_running(r2)) {
+              const int la2 = level_len(r2);
+              if (max(la, la2) <= 2 * kWave) {
+                rows &= rows - 1;
+                build_pm_table(pm, r, la);
+                build_pm_table(pm + tbl_entries, r2, la2);
+                int lcs_a, lcs_b;
+                wide_lcs2<K>(pm, pm + tbl_entries, wtext, nch, lane, max(la, la2), lcs_a, lcs_b);
+                after_step(r, la, lcs_a);
+                after_step(r2, la2, lcs_b);
+                continue;
+              }
+            }
+            build_pm_staged(r, la);
+            after_step(r, la, wide_lcs<K>(pm, wtext, nch, lane, la));
           }
         }
         for (uint32_t rows = over0; rows;) {  // pairs that finished in the wave-wide steps

@@ -186,4 +186,64 @@ __device__ __forceinline__ int wide_lcs(const unsigned long long* pm, const uint
   return wide_lcs_words<K, K, EARLY>(pm, text, nchars, lane, lb, need);
 }
 
+// Two patterns (mask tables pmA, pmB of the same layout) against the lane's text in ONE pass: the text dword,
+// the symbol extraction and the table offset are shared, and the two carry chains are independent -- at the one
+// to two waves per SIMD the 16 KB text images leave a CU, instruction-level parallelism is what hides the LDS
+// and carry latencies.  W = live words of the LONGER pattern (the shorter one's upper words have all-zero masks).
+template <int K, int W>
+__device__ __forceinline__ void wide_lcs2_words(const unsigned long long* pmA, const unsigned long long* pmB,
+                                                const uint32_t* text, int nchars, int lane, int& lcsA, int& lcsB) {
+  unsigned long long va[W], vb[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) va[k] = vb[k] = ~0ull;
+  const int nw = (nchars + 3) >> 2;
+  uint32_t w_next = nw > 0 ? text[lane] : 0u;
+  for (int w = 0; w < nw; ++w) {
+    const uint32_t word = w_next;
+    w_next = text[min(w + 1, nw - 1) * kWave + lane];
+    unsigned long long ma[4][W], mb[4][W];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int off = static_cast<int>((word >> (8 * b)) & 0xffu) * kPmWords<K>;
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        ma[b][k] = pmA[off + k];
+        mb[b][k] = pmB[off + k];
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      unsigned long long ua[W], ub[W], ta[W], tb[W];
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        ua[k] = va[k] & ma[b][k];
+        ub[k] = vb[k] & mb[b][k];
+      }
+      add_chain<W>(va, ua, ta);
+      add_chain<W>(vb, ub, tb);
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        va[k] = ta[k] | (va[k] ^ ua[k]);
+        vb[k] = tb[k] | (vb[k] ^ ub[k]);
+      }
+    }
+  }
+  int oa = 0, ob = 0;
+#pragma unroll
+  for (int k = 0; k < W; ++k) {
+    oa += __popcll(va[k]);
+    ob += __popcll(vb[k]);
+  }
+  lcsA = kWave * W - oa;
+  lcsB = kWave * W - ob;
+}
+
+// la_max = the longer of the two patterns; supported for up to 2 live words (longer pairs: two single passes)
+template <int K>
+__device__ __forceinline__ void wide_lcs2(const unsigned long long* pmA, const unsigned long long* pmB, const uint32_t* text,
+                                          int nchars, int lane, int la_max, int& lcsA, int& lcsB) {
+  if (la_max <= kWave) wide_lcs2_words<K, 1>(pmA, pmB, text, nchars, lane, lcsA, lcsB);
+  else wide_lcs2_words<K, (K >= 2 ? 2 : 1)>(pmA, pmB, text, nchars, lane, lcsA, lcsB);
+}
+
 }  // namespace nsm
