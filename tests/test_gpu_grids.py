@@ -375,6 +375,9 @@ def test_indel_levels_random(dev, max_levels):
             got = grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, capacity=1 << 11)
             _same_hits(got, want, FUZZY_TOL)
             _same_hits(got, want)
+            # without the histogram bound (NSM_FLAG_PRUNE off: weights-only bounds) and wave-wide
+            _same_hits(grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, prune=False), want)
+            _same_hits(grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, wave_wide=True), want)
 
 
 @pytest.mark.parametrize("thr", [0.0, 0.05, 0.1, 0.3])
@@ -434,6 +437,8 @@ def test_indel_levels_long_strings(dev, hi):
             got = grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, capacity=1 << 10)
             _same_hits(got, want, FUZZY_TOL)
             _same_hits(got, want)
+            _same_hits(grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, prune=False), want)
+            _same_hits(grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, wave_wide=True), want)
 
 
 def test_sort_hits_large(dev):
