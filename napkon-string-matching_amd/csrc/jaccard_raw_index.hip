@@ -25,19 +25,21 @@ struct JacIndexScalars {
   int32_t rows_per_chunk;
   unsigned long long cap;
   uint8_t kmin[2 * W + 4];  // indexed by |A|+|B|
+  uint8_t kfloor[2 * W + 4];  // min of kmin[s'] over s' >= s (kmin itself is not monotone: odd sums cannot reach 1.0)
 };
 
 #ifndef NSM_IDX_BLOOM_LOG
 #define NSM_IDX_BLOOM_LOG 16
 #endif
 #ifndef NSM_IDX_DEPTH
-#define NSM_IDX_DEPTH 1
+#define NSM_IDX_DEPTH 4
 #endif
 #ifndef NSM_IDX_WAVES
 #define NSM_IDX_WAVES 1
 #endif
 // A/B on C2 at threshold 0.1 (kernel ms): bitmap 2^13 / 14 / 15 / 16 / 17 bits at 4 (2) waves per block -> 4.47 / 4.11 /
 // 2.96 / 3.48 (2.38) / (3.06); waves per block 4 / 2 / 1 at 2^16 -> 3.48 / 2.38 / 2.05; prefetch depth 1 / 2 / 4 -> 3.93 / 4.11 / 4.31
+constexpr uint32_t kBloomMul2 = 0x85EBCA6Bu;  // second bit of the presence bitmap (two bits per id: 512 ids set 1.6 % of 2^16 bits, 0.02 % of absent ids pass)
 constexpr int32_t kEmptyKey = -3;  // ids are >= 0, padding is -1 (left) / -2 (right)
 
 template <int W>
@@ -73,6 +75,7 @@ __global__ __launch_bounds__(kBlock) void jaccard_raw_index_kernel(
   // pass only carry its lanes, so the other lanes count 0 common ids and cannot hit
   const int n_pass = tile_is_dense<W>(nrj) ? 2 : 1;
   const int jorig = rorig[jc];
+  const int nr_min = W - wave_max_i32(valid ? W - nrj : 0);  // smallest |B| of the tile (wave-uniform)
   for (int pass = 0; pass < n_pass; ++pass) {
   const bool in_pass = n_pass == 1 || (lane >> 5) == pass;
 
@@ -98,6 +101,8 @@ __global__ __launch_bounds__(kBlock) void jaccard_raw_index_kernel(
       atomicOr(&tmask[h], 1ull << lane);
       const uint32_t bit = hh >> (32 - kBloomLog);
       atomicOr(&bloom[bit >> 5], 1u << (bit & 31u));
+      const uint32_t bit2 = (static_cast<uint32_t>(id) * kBloomMul2) >> (32 - kBloomLog);
+      atomicOr(&bloom[bit2 >> 5], 1u << (bit2 & 31u));
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -106,32 +111,34 @@ __global__ __launch_bounds__(kBlock) void jaccard_raw_index_kernel(
   const int i0 = blockIdx.y * p.rows_per_chunk;
   const int i1 = min(p.n_left, i0 + p.rows_per_chunk);
   const int sub = lane / W;  // which row of the group this lane probes for
-  // the next group's ids (and its rows' sizes) are requested while the current group is probed
-  auto load_group = [&](int ig, int32_t& id, int32_t& nl) {
-    const int irow = ig + sub;
-    const bool on = irow < i1;
-    id = on ? lids[static_cast<size_t>(irow) * W + (lane & (W - 1))] : -1;
-    nl = on ? lcnt[irow] : 0;
+  // Software pipeline, kDepth groups deep: a group's ids are requested kDepth iterations before they are probed
+  // (one iteration is ~300 cycles of work, a load ~1000).  The loads are UNCONDITIONAL -- rows past the chunk's end
+  // are clamped to its last row and masked when consumed: with a predicated load the paths through an iteration
+  // hold different numbers of outstanding loads and the compiler can only wait for all of them (s_waitcnt vmcnt(0)
+  // at every group, which is why deeper queues used to be slower).  One load per group: |A| of a row is the number
+  // of its slots that hold an id (padding is -1), counted from a ballot where a row is scored.
+  auto load_group = [&](int ig) -> int32_t {
+    const int irow = min(ig + sub, i1 - 1);
+    return lids[static_cast<size_t>(irow) * W + (lane & (W - 1))];
   };
-  // software pipeline, kDepth groups deep: a group's ids are requested kDepth iterations before they are probed
-  // (one iteration is ~300 cycles of work, a global load ~1000: with one group in flight the wave waited for it)
   constexpr int kDepth = NSM_IDX_DEPTH;
-  int32_t id_q[kDepth], nl_q[kDepth];
+  int32_t id_q[kDepth];
 #pragma unroll
-  for (int d = 0; d < kDepth; ++d) load_group(i0 + d * kRowsPerGroup, id_q[d], nl_q[d]);
+  for (int d = 0; d < kDepth; ++d) id_q[d] = load_group(i0 + d * kRowsPerGroup);
   for (int ig0 = i0; ig0 < i1; ig0 += kDepth * kRowsPerGroup) {
 #pragma unroll
    for (int d = 0; d < kDepth; ++d) {
     const int ig = ig0 + d * kRowsPerGroup;
-    if (ig >= i1) break;
-    const int32_t id = id_q[d], nlv = nl_q[d];
-    load_group(ig + kDepth * kRowsPerGroup, id_q[d], nl_q[d]);
+    const int32_t id = ig + sub < i1 ? id_q[d] : -1;  // (groups past the end find nothing: no early exit, see above)
+    id_q[d] = load_group(ig + kDepth * kRowsPerGroup);
     // ---- probe: lane = (row ig + sub, id slot lane % W); the bitmap answers "not in this tile" for ~98 %
     bool found = false;
     unsigned long long m = 0ull;
     const uint32_t hh = static_cast<uint32_t>(id) * 0x9E3779B1u;
     const uint32_t bit = hh >> (32 - kBloomLog);
-    if (id >= 0 && ((bloom[bit >> 5] >> (bit & 31u)) & 1u)) {
+    const uint32_t bit2 = (static_cast<uint32_t>(id) * kBloomMul2) >> (32 - kBloomLog);
+    const uint32_t seen = (bloom[bit >> 5] >> (bit & 31u)) & (bloom[bit2 >> 5] >> (bit2 & 31u)) & 1u;  // both reads in flight together
+    if (id >= 0 && seen) {
       uint32_t h = hh >> (32 - kLog);
       for (int tries = 0; tries < T; ++tries) {
         const int32_t k = tkey[h];
@@ -147,10 +154,16 @@ __global__ __launch_bounds__(kBlock) void jaccard_raw_index_kernel(
     const unsigned long long who = __ballot(found);
     if (who == 0ull) continue;  // none of the group's ids occurs in the tile: no pair shares an id
     const uint32_t m_lo = static_cast<uint32_t>(m), m_hi = static_cast<uint32_t>(m >> 32);
+    const unsigned long long has_id = __ballot(id >= 0);
     // ---- the rows of the group that found something: |A n B| per lane = sum of the found ids' masks
     for (int rr = 0; rr < kRowsPerGroup; ++rr) {
       unsigned long long mine = (who >> (rr * W)) & ((1ull << (W % 64)) - 1ull);
       if (mine == 0ull) continue;
+      // |A n B| <= the number of the row's ids found in the tile: when that is below the smallest kmin any lane can
+      // have (kfloor[s] = min of kmin over sums >= s; nr_min = the tile's smallest row) no lane hits -- at low thresholds the usual
+      // fate of a row that shares ONE id with the tile (scalar test: no mask accumulation, no LDS read)
+      const int nl = __popcll((has_id >> (rr * W)) & ((1ull << (W % 64)) - 1ull));
+      if (__popcll(mine) < static_cast<int>(p.kfloor[nl + nr_min])) continue;
       const int i = ig + rr;
       int k = 0;
       while (mine) {
@@ -162,7 +175,6 @@ __global__ __launch_bounds__(kBlock) void jaccard_raw_index_kernel(
             static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(m_lo), q)));
         k += static_cast<int>((mq >> lane) & 1ull);
       }
-      const int nl = __builtin_amdgcn_readlane(nlv, rr * W);
       const int need = valid ? s_kmin[nl + nrj] : kNever;
       const bool hit = k >= need;
       if (__any(hit))
@@ -197,6 +209,10 @@ int launch_raw_index(const nsm_set_table* l, const nsm_set_table* r, double thre
   JacIndexScalars<W> p;
   p.n_left = l->n; p.n_right = r->n; p.cap = capacity;
   index_fill_kmin<W>(p.kmin, threshold);
+  for (int s = 2 * W + 3, lo = kNever; s >= 0; --s) {
+    lo = p.kmin[s] < lo ? p.kmin[s] : lo;
+    p.kfloor[s] = static_cast<uint8_t>(lo);
+  }
   constexpr int T = index_slots<W>();
   const int waves = W == 16 ? NSM_IDX_WAVES : 2;  // 12 / 24 KB of table per wave
   const int n_tiles = (r->n + kWave - 1) / kWave;
