@@ -25,7 +25,8 @@ struct JacIndexScalars {
   int32_t rows_per_chunk;
   unsigned long long cap;
   uint8_t kmin[2 * W + 4];  // indexed by |A|+|B|
-  uint8_t kfloor[2 * W + 4];  // min of kmin[s'] over s' >= s (kmin itself is not monotone: odd sums cannot reach 1.0)
+  int32_t kfloor[2 * W + 4];  // min of kmin[s'] over s' >= s (kmin itself is not monotone: odd sums cannot reach 1.0); dwords: scalar loads
+  int32_t one_id_from;        // smallest s with kfloor[s] > 1
 };
 
 #ifndef NSM_IDX_BLOOM_LOG
@@ -131,13 +132,31 @@ __global__ __launch_bounds__(kBlock) void jaccard_raw_index_kernel(
     const int ig = ig0 + d * kRowsPerGroup;
     const int32_t id = ig + sub < i1 ? id_q[d] : -1;  // (groups past the end find nothing: no early exit, see above)
     id_q[d] = load_group(ig + kDepth * kRowsPerGroup);
-    // ---- probe: lane = (row ig + sub, id slot lane % W); the bitmap answers "not in this tile" for ~98 %
-    bool found = false;
-    unsigned long long m = 0ull;
+    // ---- presence test: lane = (row ig + sub, id slot lane % W); the bitmap answers "not in this tile" for ~99.6 %
     const uint32_t hh = static_cast<uint32_t>(id) * 0x9E3779B1u;
     const uint32_t bit = hh >> (32 - kBloomLog);
     const uint32_t bit2 = (static_cast<uint32_t>(id) * kBloomMul2) >> (32 - kBloomLog);
     const uint32_t seen = (bloom[bit >> 5] >> (bit & 31u)) & (bloom[bit2 >> 5] >> (bit2 & 31u)) & 1u;  // both reads in flight together
+    const unsigned long long maybe = __ballot(id >= 0 && seen);
+    if (maybe == 0ull) continue;  // none of the group's ids occurs in the tile: no pair shares an id
+    // ---- |A n B| <= the number of the row's ids that pass the bitmap.  When that is below the smallest kmin any lane can
+    // have (kfloor[s] = min of kmin over sums >= s; nr_min = the tile's smallest row) no lane hits: at low thresholds the
+    // usual fate of a row that shares ONE id with the tile, decided on the scalar unit -- no hash probe, no mask
+    // accumulation, no memory access (p.one_id_from = the smallest |A| + |B| from which a single common id is too few)
+    const unsigned long long has_id = __ballot(id >= 0);
+    uint32_t rows_go = 0;
+    for (int rr = 0; rr < kRowsPerGroup; ++rr) {
+      const unsigned long long seg = (maybe >> (rr * W)) & ((1ull << (W % 64)) - 1ull);
+      if (seg == 0ull) continue;
+      const int nl = __popcll((has_id >> (rr * W)) & ((1ull << (W % 64)) - 1ull));
+      const int upto = __popcll(seg);
+      const bool too_few = upto == 1 ? nl + nr_min >= p.one_id_from : upto < p.kfloor[nl + nr_min];
+      if (!too_few) rows_go |= 1u << rr;
+    }
+    if (rows_go == 0u) continue;
+    // ---- probe the hash table: the lane masks of the ids that are really there
+    bool found = false;
+    unsigned long long m = 0ull;
     if (id >= 0 && seen) {
       uint32_t h = hh >> (32 - kLog);
       for (int tries = 0; tries < T; ++tries) {
@@ -152,18 +171,12 @@ __global__ __launch_bounds__(kBlock) void jaccard_raw_index_kernel(
       }
     }
     const unsigned long long who = __ballot(found);
-    if (who == 0ull) continue;  // none of the group's ids occurs in the tile: no pair shares an id
     const uint32_t m_lo = static_cast<uint32_t>(m), m_hi = static_cast<uint32_t>(m >> 32);
-    const unsigned long long has_id = __ballot(id >= 0);
-    // ---- the rows of the group that found something: |A n B| per lane = sum of the found ids' masks
+    // ---- the rows that may hit: |A n B| per lane = sum of the found ids' masks
     for (int rr = 0; rr < kRowsPerGroup; ++rr) {
       unsigned long long mine = (who >> (rr * W)) & ((1ull << (W % 64)) - 1ull);
-      if (mine == 0ull) continue;
-      // |A n B| <= the number of the row's ids found in the tile: when that is below the smallest kmin any lane can
-      // have (kfloor[s] = min of kmin over sums >= s; nr_min = the tile's smallest row) no lane hits -- at low thresholds the usual
-      // fate of a row that shares ONE id with the tile (scalar test: no mask accumulation, no LDS read)
+      if (mine == 0ull || !((rows_go >> rr) & 1u)) continue;
       const int nl = __popcll((has_id >> (rr * W)) & ((1ull << (W % 64)) - 1ull));
-      if (__popcll(mine) < static_cast<int>(p.kfloor[nl + nr_min])) continue;
       const int i = ig + rr;
       int k = 0;
       while (mine) {
@@ -211,8 +224,10 @@ int launch_raw_index(const nsm_set_table* l, const nsm_set_table* r, double thre
   index_fill_kmin<W>(p.kmin, threshold);
   for (int s = 2 * W + 3, lo = kNever; s >= 0; --s) {
     lo = p.kmin[s] < lo ? p.kmin[s] : lo;
-    p.kfloor[s] = static_cast<uint8_t>(lo);
+    p.kfloor[s] = lo;
   }
+  p.one_id_from = 2 * W + 4;
+  for (int s = 2 * W + 3; s >= 0 && p.kfloor[s] > 1; --s) p.one_id_from = s;
   constexpr int T = index_slots<W>();
   const int waves = W == 16 ? NSM_IDX_WAVES : 2;  // 12 / 24 KB of table per wave
   const int n_tiles = (r->n + kWave - 1) / kWave;
