@@ -373,7 +373,8 @@ int launch_raw(const nsm_set_table* l, const nsm_set_table* r, double threshold,
     // Low thresholds: the signature bound passes too often for typical set sizes (the mid-size class is "weak"),
     // every pair would pay the position matrix.  Candidate generation by inverted index instead.
     const bool weak_mid = (p.weak[W / 2] >> (W / 2)) & 1ull;
-    const bool use_index = threshold > 0.0 && !(flags & NSM_FLAG_NO_INDEX) &&
+    // (the index kernel addresses the left ids with 32-bit byte offsets)
+    const bool use_index = threshold > 0.0 && !(flags & NSM_FLAG_NO_INDEX) && static_cast<long long>(l->n) * W * 4 < (1ll << 32) &&
                            ((flags & NSM_FLAG_INDEX) || ((flags & NSM_FLAG_PRUNE) && weak_mid));
     if (use_index) {
       return launch_raw_index<W>(l, r, threshold, hits, capacity, hit_count, stream);

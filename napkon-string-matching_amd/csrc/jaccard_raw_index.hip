@@ -30,7 +30,7 @@ struct JacIndexScalars {
 };
 
 #ifndef NSM_IDX_BLOOM_LOG
-#define NSM_IDX_BLOOM_LOG 16
+#define NSM_IDX_BLOOM_LOG 15
 #endif
 #ifndef NSM_IDX_DEPTH
 #define NSM_IDX_DEPTH 4
@@ -38,9 +38,15 @@ struct JacIndexScalars {
 #ifndef NSM_IDX_WAVES
 #define NSM_IDX_WAVES 1
 #endif
-// A/B on C2 at threshold 0.1 (kernel ms): bitmap 2^13 / 14 / 15 / 16 / 17 bits at 4 (2) waves per block -> 4.47 / 4.11 /
-// 2.96 / 3.48 (2.38) / (3.06); waves per block 4 / 2 / 1 at 2^16 -> 3.48 / 2.38 / 2.05; prefetch depth 1 / 2 / 4 -> 3.93 / 4.11 / 4.31
-constexpr uint32_t kBloomMul2 = 0x85EBCA6Bu;  // second bit of the presence bitmap (two bits per id: 512 ids set 1.6 % of 2^16 bits, 0.02 % of absent ids pass)
+// A/B on C2 at threshold 0.1 (kernel ms).  First version (one bit per id, probe on every bitmap pass, one group of ids in
+// flight): bitmap 2^13 / 14 / 15 / 16 / 17 bits at 4 (2) waves per block -> 4.47 / 4.11 / 2.96 / 3.48 (2.38) / (3.06); waves per
+// block 4 / 2 / 1 at 2^16 -> 3.48 / 2.38 / 2.05.  Then, at 1 wave per block: unconditional 4-deep id queue 1.94; two bits per
+// id + scalar reject of rows that found one id 1.48; reject from the bitmap's pass count before probing 1.19; bitmap
+// 2^13 / 14 / 15 / 16 / 17 -> 1.22 / 1.10 / 1.08 / 1.19 / 1.43 (LDS per wave decides the occupancy); both bits from one
+// product + 32-bit load offsets 1.03; queue depth 2 / 4 / 8 -> 1.21 / 1.19 / 1.18; waves per block 1 / 2 / 4 -> 1.19 / 1.33 / 1.81.
+// Second bit of the presence bitmap: another field of the same product (a 32-bit multiply is a quarter-rate op).  Two
+// bits per id: 512 ids set 3 % of 2^15 bits, 0.1 % of absent ids pass.
+constexpr int kBloom2Shift = 1;
 constexpr int32_t kEmptyKey = -3;  // ids are >= 0, padding is -1 (left) / -2 (right)
 
 template <int W>
@@ -53,7 +59,7 @@ __global__ __launch_bounds__(kBlock) void jaccard_raw_index_kernel(
   constexpr int kRowsPerGroup = kWave / W;  // left rows probed at once (W = 16: 4, W = 32: 2)
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_idx[];
   // per wave: [T] u64 masks | [T] i32 keys | [kBloomWords] u32 presence bitmap; then kmin
-  constexpr int kBloomLog = NSM_IDX_BLOOM_LOG;  // presence bitmap: 2^16 bits = 8 KB, < 1 % of absent ids pass at 512 ids per tile
+  constexpr int kBloomLog = NSM_IDX_BLOOM_LOG;  // presence bitmap: 2^15 bits = 4 KB per wave
   constexpr int kBloomWords = (1 << kBloomLog) / 32;
   constexpr int kWaveWords = T + T / 2 + kBloomWords / 2;  // u64 units
   const int waves = blockDim.x >> 6;
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(kBlock) void jaccard_raw_index_kernel(
       atomicOr(&tmask[h], 1ull << lane);
       const uint32_t bit = hh >> (32 - kBloomLog);
       atomicOr(&bloom[bit >> 5], 1u << (bit & 31u));
-      const uint32_t bit2 = (static_cast<uint32_t>(id) * kBloomMul2) >> (32 - kBloomLog);
+      const uint32_t bit2 = (hh >> kBloom2Shift) & ((1u << kBloomLog) - 1u);
       atomicOr(&bloom[bit2 >> 5], 1u << (bit2 & 31u));
     }
   }
@@ -118,9 +124,11 @@ __global__ __launch_bounds__(kBlock) void jaccard_raw_index_kernel(
   // hold different numbers of outstanding loads and the compiler can only wait for all of them (s_waitcnt vmcnt(0)
   // at every group, which is why deeper queues used to be slower).  One load per group: |A| of a row is the number
   // of its slots that hold an id (padding is -1), counted from a ballot where a row is scored.
+  const uint32_t slot_off = static_cast<uint32_t>(lane & (W - 1)) * 4u;
   auto load_group = [&](int ig) -> int32_t {
-    const int irow = min(ig + sub, i1 - 1);
-    return lids[static_cast<size_t>(irow) * W + (lane & (W - 1))];
+    // 32-bit byte offset from the uniform base: one address op per load (the launcher checks n_left * W * 4 < 2^32)
+    const uint32_t off = static_cast<uint32_t>(min(ig + sub, i1 - 1)) * (W * 4u) + slot_off;
+    return *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(lids) + off);
   };
   constexpr int kDepth = NSM_IDX_DEPTH;
   int32_t id_q[kDepth];
@@ -135,7 +143,7 @@ __global__ __launch_bounds__(kBlock) void jaccard_raw_index_kernel(
     // ---- presence test: lane = (row ig + sub, id slot lane % W); the bitmap answers "not in this tile" for ~99.6 %
     const uint32_t hh = static_cast<uint32_t>(id) * 0x9E3779B1u;
     const uint32_t bit = hh >> (32 - kBloomLog);
-    const uint32_t bit2 = (static_cast<uint32_t>(id) * kBloomMul2) >> (32 - kBloomLog);
+    const uint32_t bit2 = (hh >> kBloom2Shift) & ((1u << kBloomLog) - 1u);
     const uint32_t seen = (bloom[bit >> 5] >> (bit & 31u)) & (bloom[bit2 >> 5] >> (bit2 & 31u)) & 1u;  // both reads in flight together
     const unsigned long long maybe = __ballot(id >= 0 && seen);
     if (maybe == 0ull) continue;  // none of the group's ids occurs in the tile: no pair shares an id
