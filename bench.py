@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: pair-comparisons/sec of the all-pairs match loop on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c2low|c3|c4|c5|term] [--no-cpu-baseline]
 
 N > 1 is launched by the driver as
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -64,7 +64,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=("c2", "c3", "c4", "c5", "term"), default="c2")
+    ap.add_argument("--workload", choices=("c2", "c2low", "c3", "c4", "c5", "term"), default="c2")
     ap.add_argument("--rows", type=int, default=0, help="override rows per side per GPU (debug)")
     ap.add_argument("--right-rows", type=int, default=0, help="override the right side's rows (debug)")
     ap.add_argument("--threshold", type=float, default=None, help="override the workload's threshold (debug)")
@@ -102,7 +102,9 @@ class Workload:
             rows = -(-total // world)
             threshold = 0.8 if threshold is None else threshold
             self.scaling = "strong"
-        if name in ("c2", "c4"):
+        if name == "c2low":  # configs[1]'s grid at the API's default score_threshold (types/comparable_data.py:74)
+            threshold = 0.1 if threshold is None else threshold
+        if name in ("c2", "c2low", "c4"):
             n = rows or 50_000
             m = right_rows or rows or 50_000
             self.threshold = 0.5 if threshold is None else threshold
@@ -127,6 +129,8 @@ class Workload:
             self.launch_fn = self.lib.nsm_jaccard_raw_grid
             self.kernel = "jaccard_raw_kernel<16>"
             self.kernel_match, self.kernel_match_exhaustive = "jaccard_raw_kernel<16, true>", "jaccard_raw_kernel<16, false>"
+            if name == "c2low":  # low thresholds: candidates from the per-tile inverted index
+                self.kernel = self.kernel_match = "jaccard_raw_index_kernel<16>"
             self.dtype = "int32"
             self.label = (f"{name.upper()}: {n}x{m} token-id sets/GPU (Poisson(8) ids, W=16), intersection_vs_union RAW, "
                           f"threshold {self.threshold}")
@@ -371,7 +375,7 @@ def cpu_baseline(work, budget_pairs):
     from napkon_string_matching_amd import synthetic
     from oracle import compare as oc
 
-    if work.name in ("c2", "c4"):
+    if work.name in ("c2", "c2low", "c4"):
         side = int(budget_pairs ** 0.5)
         left = synthetic.decode_sets(work.left_np[:side])
         right = synthetic.decode_sets(work.right_np[:side])
@@ -598,11 +602,11 @@ def run_raw(args, comm, device, name, rows=0, right_rows=0, threshold=None, step
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
     capacity = args.capacity
-    if name == "c4" and capacity == 1 << 13:
-        capacity = 1 << 16  # ~12k hits at 1M x 1M
+    if name in ("c4", "c2low") and capacity == 1 << 13:
+        capacity = 1 << 16  # ~12k hits at 1M x 1M; ~53k at 50k x 50k and threshold 0.1
     if name == "term" and capacity == 1 << 13:
         capacity = 1 << 24  # ~2.6 % of the pairs reach the cache threshold 0.5
-    work = Workload(name, comm, rows, device, right_rows, threshold, getattr(args, "id_range", 0) if name in ("c2", "c4") else 0)
+    work = Workload(name, comm, rows, device, right_rows, threshold, getattr(args, "id_range", 0) if name in ("c2", "c2low", "c4") else 0)
     # the committed profile describes the workload's default per-GPU grid (c4 divides its rows over the ranks)
     default_shape = (not rows and not right_rows and threshold is None and (name != "c4" or world == 1)
                      and not getattr(args, "id_range", 0))

@@ -36,9 +36,9 @@ def _check_roofline(roof, need_frac):
         assert not need_frac, roof
 
 
-@pytest.mark.parametrize("workload", ["c2", "c3", "c4", "c5", "term"])
+@pytest.mark.parametrize("workload", ["c2", "c2low", "c3", "c4", "c5", "term"])
 def test_bench_line(workload):
-    rows = {"c2": "8000", "c3": "8000", "c4": "60000", "c5": "6000", "term": "3000"}[workload]
+    rows = {"c2": "8000", "c2low": "8000", "c3": "8000", "c4": "60000", "c5": "6000", "term": "3000"}[workload]
     d = _line([sys.executable, "bench.py", "--workload", workload, "--rows", rows, "--steps", "2", "--warmup", "1"])
     assert all(k in d for k in CONTRACT), sorted(d)
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["higher_is_better"] is True
@@ -47,7 +47,7 @@ def test_bench_line(workload):
     _check_roofline(d["roofline"], need_frac=False)  # reduced grid: the committed profile does not apply
     cpu = d["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["value"] > 0 and cpu["sample"]
-    assert d["scaling"] == ("weak" if workload in ("c2", "c3", "term") else "strong")
+    assert d["scaling"] == ("weak" if workload in ("c2", "c2low", "c3", "term") else "strong")
 
 
 def test_bench_default_roofline_is_a_fraction():

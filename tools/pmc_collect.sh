@@ -7,7 +7,7 @@
 set -e -o pipefail
 export TMPDIR=/tmp
 out=${1:-gpurun_out/pmc}; stamp=${2:-unknown}; shift 2 || true
-loads=${@:-c2 c3 levels term}
+loads=${@:-c2 c2low c3 levels term}
 mkdir -p $out
 SQ_A="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"
 SQ_B="SQ_WAVES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE"

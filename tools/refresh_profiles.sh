@@ -15,7 +15,7 @@ for part in $parts; do
   case $part in
   bench)
     python3 bench.py > $out/c2_bench.json 2> $out/c2_bench.err; echo "c2 bench done"
-    for w in c3 c4 term; do python3 bench.py --workload $w > $out/${w}_bench.json 2> $out/${w}_bench.err; echo "$w bench done"; done
+    for w in c2low c3 c4 term; do python3 bench.py --workload $w > $out/${w}_bench.json 2> $out/${w}_bench.err; echo "$w bench done"; done
     python3 bench.py --workload c5 --steps 3 --warmup 1 > $out/c5_bench.json 2> $out/c5_bench.err; echo "c5 bench done"
     python3 tools/bench_levels.py --rows 100000 --steps 5 --check 300 > $out/levels_bench.json 2> $out/levels_bench.err; echo "levels bench done"
     python3 tools/bench_terms.py --rows 50000 --check 200 > $out/terms_bench.json 2> $out/terms_bench.err; echo "terms bench done"
@@ -31,7 +31,7 @@ for part in $parts; do
     done
     ;;
   pmc)
-    tools/pmc_collect.sh $out $stamp c2 c3 c4 c5 term levels
+    tools/pmc_collect.sh $out $stamp c2 c2low c3 c4 c5 term levels
     ;;
   esac
 done
