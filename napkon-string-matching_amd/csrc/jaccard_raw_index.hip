@@ -36,7 +36,7 @@ struct JacIndexScalars {
 #define NSM_IDX_DEPTH 4
 #endif
 #ifndef NSM_IDX_WAVES
-#define NSM_IDX_WAVES 1
+#define NSM_IDX_WAVES 4
 #endif
 // A/B on C2 at threshold 0.1 (kernel ms).  First version (one bit per id, probe on every bitmap pass, one group of ids in
 // flight): bitmap 2^13 / 14 / 15 / 16 / 17 bits at 4 (2) waves per block -> 4.47 / 4.11 / 2.96 / 3.48 (2.38) / (3.06); waves per
@@ -58,22 +58,22 @@ __global__ __launch_bounds__(kBlock) void jaccard_raw_index_kernel(
   constexpr int kLog = W == 16 ? 10 : 11;
   constexpr int kRowsPerGroup = kWave / W;  // left rows probed at once (W = 16: 4, W = 32: 2)
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_idx[];
-  // per wave: [T] u64 masks | [T] i32 keys | [kBloomWords] u32 presence bitmap; then kmin
-  constexpr int kBloomLog = NSM_IDX_BLOOM_LOG;  // presence bitmap: 2^15 bits = 4 KB per wave
+  // per BLOCK (its waves share one right tile and take different chunks of left rows, so the index is built once
+  // for all of them and a CU holds 8 waves per SIMD instead of 2.5): [T] u64 masks | [T] i32 keys | [kBloomWords] u32
+  // presence bitmap; then kmin
+  constexpr int kBloomLog = NSM_IDX_BLOOM_LOG;  // presence bitmap: 2^15 bits = 4 KB
   constexpr int kBloomWords = (1 << kBloomLog) / 32;
-  constexpr int kWaveWords = T + T / 2 + kBloomWords / 2;  // u64 units
+  constexpr int kTableWords = T + T / 2 + kBloomWords / 2;  // u64 units
   const int waves = blockDim.x >> 6;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
-  unsigned long long* tmask = s_idx + static_cast<size_t>(wave) * kWaveWords;
+  unsigned long long* tmask = s_idx;
   int32_t* tkey = reinterpret_cast<int32_t*>(tmask + T);
   uint32_t* bloom = reinterpret_cast<uint32_t*>(tkey + T);
-  uint8_t* s_kmin = reinterpret_cast<uint8_t*>(s_idx + static_cast<size_t>(waves) * kWaveWords);
+  uint8_t* s_kmin = reinterpret_cast<uint8_t*>(s_idx + kTableWords);
   for (int t = threadIdx.x; t < 2 * W + 4; t += blockDim.x) s_kmin[t] = p.kmin[t];
-  __syncthreads();
 
-  const int tile = blockIdx.x * waves + wave;
-  if (tile * kWave >= p.n_right) return;  // whole wave
+  const int tile = blockIdx.x;  // (block-uniform: every wave reaches every barrier below)
   const int j = tile * kWave + lane;
   const bool valid = j < p.n_right;
   const int jc = valid ? j : p.n_right - 1;
@@ -86,17 +86,16 @@ __global__ __launch_bounds__(kBlock) void jaccard_raw_index_kernel(
   for (int pass = 0; pass < n_pass; ++pass) {
   const bool in_pass = n_pass == 1 || (lane >> 5) == pass;
 
-  // ---- build: every lane inserts its row's ids (hash table + presence bitmap)
-  for (int c = lane; c < T; c += kWave) {
+  // ---- build: every lane inserts its row's ids (hash table + presence bitmap), the block's waves take turns on the slots
+  for (int c = threadIdx.x; c < T; c += blockDim.x) {
     tmask[c] = 0ull;
     tkey[c] = kEmptyKey;
   }
-  for (int c = lane; c < kBloomWords; c += kWave) bloom[c] = 0u;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+  for (int c = threadIdx.x; c < kBloomWords; c += blockDim.x) bloom[c] = 0u;
+  __syncthreads();
   {
     const int32_t* rrow = rids + static_cast<size_t>(jc) * W;
-    for (int q = 0; q < (in_pass ? nrj : 0); ++q) {
+    for (int q = wave; q < (in_pass ? nrj : 0); q += waves) {
       const int32_t id = rrow[q];
       const uint32_t hh = static_cast<uint32_t>(id) * 0x9E3779B1u;
       uint32_t h = hh >> (32 - kLog);
@@ -112,11 +111,11 @@ __global__ __launch_bounds__(kBlock) void jaccard_raw_index_kernel(
       atomicOr(&bloom[bit2 >> 5], 1u << (bit2 & 31u));
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+  __syncthreads();
 
-  const int i0 = blockIdx.y * p.rows_per_chunk;
+  const int i0 = (blockIdx.y * waves + wave) * p.rows_per_chunk;
   const int i1 = min(p.n_left, i0 + p.rows_per_chunk);
+  if (i0 < i1) {  // (the last block's spare waves have no chunk)
   const int sub = lane / W;  // which row of the group this lane probes for
   // Software pipeline, kDepth groups deep: a group's ids are requested kDepth iterations before they are probed
   // (one iteration is ~300 cycles of work, a load ~1000).  The loads are UNCONDITIONAL -- rows past the chunk's end
@@ -203,8 +202,8 @@ __global__ __launch_bounds__(kBlock) void jaccard_raw_index_kernel(
     }
    }
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the table is rebuilt by the next pass
-  __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();  // the table is rebuilt by the next pass
   }
 }
 
@@ -237,18 +236,20 @@ int launch_raw_index(const nsm_set_table* l, const nsm_set_table* r, double thre
   p.one_id_from = 2 * W + 4;
   for (int s = 2 * W + 3; s >= 0 && p.kfloor[s] > 1; --s) p.one_id_from = s;
   constexpr int T = index_slots<W>();
-  const int waves = W == 16 ? NSM_IDX_WAVES : 2;  // 12 / 24 KB of table per wave
+  const int waves = NSM_IDX_WAVES;
   const int n_tiles = (r->n + kWave - 1) / kWave;
-  // the table is rebuilt per (tile, chunk): long chunks, but enough blocks to fill the chip
+  // the table is rebuilt per (tile, waves chunks): long chunks, but enough blocks to fill the chip
   long long rows = 2048;
-  while (rows > 256 && static_cast<long long>((n_tiles + waves - 1) / waves) * ((l->n + rows - 1) / rows) < 4096) rows /= 2;
+  auto blocks = [&](long long rows_per_chunk) {
+    const long long chunks = (l->n + rows_per_chunk - 1) / rows_per_chunk;
+    return static_cast<long long>(n_tiles) * ((chunks + waves - 1) / waves);
+  };
+  while (rows > 256 && blocks(rows) < 4096) rows /= 2;
+  while ((l->n + rows - 1) / rows > 65535ll * waves) rows *= 2;
   p.rows_per_chunk = static_cast<int>(rows);
-  dim3 grid((n_tiles + waves - 1) / waves, (l->n + p.rows_per_chunk - 1) / p.rows_per_chunk);
-  if (grid.y > 65535) {
-    p.rows_per_chunk = (l->n + 65534) / 65535;
-    grid.y = (l->n + p.rows_per_chunk - 1) / p.rows_per_chunk;
-  }
-  const size_t lds = static_cast<size_t>(waves) * (T + T / 2 + (1 << NSM_IDX_BLOOM_LOG) / 64) * 8 + 2 * W + 4;  // + the presence bitmap per wave
+  const long long chunks = (l->n + rows - 1) / rows;
+  dim3 grid(n_tiles, static_cast<unsigned>((chunks + waves - 1) / waves));
+  const size_t lds = static_cast<size_t>(T + T / 2 + (1 << NSM_IDX_BLOOM_LOG) / 64) * 8 + 2 * W + 4;
   hipLaunchKernelGGL((jaccard_raw_index_kernel<W>), grid, dim3(waves * kWave), lds, stream, l->ids, l->cnt, l->orig, r->ids,
                      r->cnt, r->orig, hits, hit_count, p);
   return hip_status(hipGetLastError(), "jaccard_raw_index_kernel launch");
