@@ -44,6 +44,8 @@ struct JacIndexScalars {
 // id + scalar reject of rows that found one id 1.48; reject from the bitmap's pass count before probing 1.19; bitmap
 // 2^13 / 14 / 15 / 16 / 17 -> 1.22 / 1.10 / 1.08 / 1.19 / 1.43 (LDS per wave decides the occupancy); both bits from one
 // product + 32-bit load offsets 1.03; queue depth 2 / 4 / 8 -> 1.21 / 1.19 / 1.18; waves per block 1 / 2 / 4 -> 1.19 / 1.33 / 1.81.
+// One index per BLOCK (4 waves, 4 chunks; 16 KB per block instead of per wave): 0.83; bitmap 2^15 / 16 / 17 then 0.83 / 0.83 /
+// 0.85, 2 waves per block 0.89.
 // Second bit of the presence bitmap: another field of the same product (a 32-bit multiply is a quarter-rate op).  Two
 // bits per id: 512 ids set 3 % of 2^15 bits, 0.1 % of absent ids pass.
 constexpr int kBloom2Shift = 1;
@@ -239,7 +241,10 @@ int launch_raw_index(const nsm_set_table* l, const nsm_set_table* r, double thre
   const int waves = NSM_IDX_WAVES;
   const int n_tiles = (r->n + kWave - 1) / kWave;
   // the table is rebuilt per (tile, waves chunks): long chunks, but enough blocks to fill the chip
-  long long rows = 2048;
+#ifndef NSM_IDX_ROWS
+#define NSM_IDX_ROWS 1536  // 1024 ... 3072: 0.81 ms, 2048 and 4096: 0.83 (how the blocks fill the last round)
+#endif
+  long long rows = NSM_IDX_ROWS;
   auto blocks = [&](long long rows_per_chunk) {
     const long long chunks = (l->n + rows_per_chunk - 1) / rows_per_chunk;
     return static_cast<long long>(n_tiles) * ((chunks + waves - 1) / waves);
