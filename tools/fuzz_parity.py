@@ -86,6 +86,10 @@ def main():
         n, m = rng.randint(1, 400), rng.randint(1, 600)
         if family == "jaccard_raw":
             width = rng.choice([16, 16, 32, 64])
+            # the inverted-index kernel (low thresholds) on request too, and with several chunks of left rows per block
+            index = True if (width < 64 and thr > 0 and rng.random() < 0.3) else None
+            if index and rng.random() < 0.4:
+                n = rng.randint(1500, 7000)
             kmax = rng.randint(1, width)
             vocab = rng.choice([kmax + 1, 3 * kmax, 50 * kmax, 100_000])
             left = rand_sets(rng, n, kmax, vocab, allow_empty=False)
@@ -102,8 +106,8 @@ def main():
             rt = tables.SetTable.from_padded(pad(right), "right", dev, width=width)
             want = native.jaccard_raw(native.csr(left), native.csr(right), thr, cap=1 << 19)
             prune = rng.random() < 0.7
-            check(grid.jaccard_raw_grid(lt, rt, thr, prune=prune, capacity=rng.choice([64, 4096, 1 << 16])), want,
-                  f"jaccard_raw W={width} kmax={kmax} vocab={vocab} thr={thr} prune={prune} {n}x{m}")
+            check(grid.jaccard_raw_grid(lt, rt, thr, prune=prune, capacity=rng.choice([64, 4096, 1 << 16]), index=index), want,
+                  f"jaccard_raw W={width} kmax={kmax} vocab={vocab} thr={thr} prune={prune} index={index} {n}x{m}")
         elif family == "indel_raw":
             hi = rng.choice([8, 30, 64, 64, 100, 128, 200, 256, 400, 512])
             alphabet = rng.choice(["ab", "abcdefgh ", "abcdefghijklmnopqrstuvwxyz0123456789 ", "".join(chr(0x100 + k) for k in range(150))])
