@@ -130,6 +130,11 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
   constexpr int kBatch = park_batch(K);
   constexpr int kSub = park_sub(K);
   constexpr int NB = (K == 1) ? 4 : 8;  // histogram dwords per level string
+#ifndef NSM_STAGE_EARLY
+#define NSM_STAGE_EARLY 1
+#endif
+  constexpr bool kStageEarly = NSM_STAGE_EARLY != 0;
+  constexpr bool kPrefetchRows = false;
   const int waves = blockDim.x >> 6;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
@@ -217,6 +222,7 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
   uint32_t taddr[K == 1 ? 32 : 1];
   int text_row = -1;
   int lb = 0;
+  int pre_ib = -1, pre_ll = 0, pre_lf = 0;
 
   auto ratio_of = [](int la_, int lb_, int lcs_) -> double {
     // (the index is clamped: an idle lane's operands must never turn into a wild read)
@@ -441,10 +447,36 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
     return;
 #endif
     // ---- stage: heads of the batch's rows (lane = (row, step 1..3))
+    // One-word strings: the step-1 level strings of ALL the batch's rows ride along (lanes 24..55 = 16 bytes of a row
+    // each), one dependent load behind the row's (first, depth) like the heads -- staging them after the H phase, for
+    // the rows with a live lane only, was a third dependent round trip per batch, and at configs[4]'s survival rate
+    // every row has a live lane (3 x 100k^2: 20.95 -> 20.6 ms).  The (first, depth) loads are UNCONDITIONAL, rows past
+    // the batch clamped: inside the lane-dependent branches each branch waited for its own round trips, one branch
+    // after the other (20.6 -> 19.1 ms).  Tried on top and dropped: the second-level loads unconditional too (every
+    // lane loads a histogram, a length and 16 bytes of string: 20.2 ms); (first, depth) requested one batch ahead
+    // and kept in two registers across the scan (19.7 ms).
+    // (Spelled exactly like this on purpose: at the 128 registers of 4 waves per SIMD the one-word kernel spills a
+    // little, and WHERE it spills moves with the spelling -- the same statements with the row index reused in the
+    // branches measured 20.4 ms.)
+    const int my_r = lane < 3 * kBatch ? lane / 3 : (lane - 3 * kBatch) >> 2;
+    int cur_ll, cur_lf;
+    if (kPrefetchRows && pre_ib == ib) {
+      cur_ll = pre_ll;
+      cur_lf = pre_lf;
+    } else {
+      const int i = min(ib + my_r, p.n_left - 1);
+      cur_ll = lnlev[i];
+      cur_lf = lfirst[i];
+    }
+    if (kPrefetchRows) {  // (first, depth) of the next batch's rows one batch ahead: measured slower, compiled out
+      const int i = min(ib + kBatch + my_r, p.n_left - 1);
+      pre_ll = lnlev[i];
+      pre_lf = lfirst[i];
+      pre_ib = ib + kBatch;
+    }
     if (lane < nrows * 3) {
       const int r = lane / 3, t = lane - 3 * r;
-      const int i = ib + r;
-      const int ll = lnlev[i], lf = lfirst[i];
+      const int ll = cur_ll, lf = cur_lf;
       const int lrow = lf + max(0, min(t + 1, ll - 1));
       uint32_t h[NB];
       if (use_hist) load_hist<NB>(lhist, lrow, h);
@@ -458,6 +490,10 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
       rec[NB + 1] = static_cast<uint32_t>(lrow);
       rec[NB + 2] = static_cast<uint32_t>(ll);
       rec[NB + 3] = static_cast<uint32_t>(lf);
+    } else if (K == 1 && kStageEarly && lane >= 3 * kBatch && lane < 3 * kBatch + 4 * nrows) {
+      const int q = lane - 3 * kBatch, r = q >> 2, part = q & 3;
+      const int lrow = cur_lf + max(0, min(1, cur_ll - 1));
+      reinterpret_cast<uint4*>(lstr + r * kRow)[part] = reinterpret_cast<const uint4*>(lcodes + static_cast<size_t>(lrow) * kRow)[part];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -505,7 +541,7 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
 #endif
 
     // ---- step 1, wave-wide
-    stage_strings(ib, live, 1);
+    if (!(K == 1 && kStageEarly)) stage_strings(ib, live, 1);
     const int rrow = rrow0 + max(0, min(1, lr - 1));
     if constexpr (K == 1) {
       if (rrow != text_row) {  // step 1 reads the same right level for every batch
@@ -845,6 +881,8 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
         const int ib = sb + g * kBatch;
         if (ib >= b) break;
         const int nrows = min(kBatch, b - ib);
+        // (the rows' category masks as scalar loads: one vector load + v_readlane per row, issued together with the
+        // staging lanes' (depth, first) loads, was slower: 20.5 vs 19.1 ms)
         uint32_t okbits = 0, rows_ok = 0;
         for (int r = 0; r < nrows; ++r) {
           const uint64_t cl = (p.cat_mode != NSM_CAT_NONE) ? lcat[ib + r] : 0ull;
