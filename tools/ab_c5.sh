@@ -1,5 +1,8 @@
-V=napkon-string-matching_amd/csrc/variants
-for lib in - $V/libnsm_sl4k.so $V/libnsm_sl16k.so $V/libnsm_sl32k.so $V/libnsm_pm16.so $V/libnsm_pm32.so -; do
+#!/bin/bash
+# same-box comparison of builds of the library on configs[4] (bench.py --workload c5):
+#   tools/ab_c5.sh lib_a.so lib_b.so ...      ("-" = the in-tree build)   ->  name, step ms, fuzzy grids ms, Jaccard grids ms
+show='import sys,json; d=json.loads(sys.stdin.read()); print("%-24s step %7.1f ms  fuzzy %7.1f ms  jaccard %6.1f ms" % (sys.argv[1], d["ms_per_step"], d["config"]["fuzzy_grids_ms_per_step"], d["config"]["jaccard_grids_ms_per_step"]))'
+for lib in "$@"; do
   if [ "$lib" = "-" ]; then unset NSM_HIP_LIBRARY; else export NSM_HIP_LIBRARY=$lib; fi
-  timeout -k 10 300 python bench.py --workload c5 --steps 3 --no-cpu-baseline 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(sys.argv[1], round(d["ms_per_step"],1), round(d["config"]["fuzzy_grids_ms_per_step"],1), round(d["config"]["jaccard_grids_ms_per_step"],1))' $(basename $lib) || exit 1
+  timeout -k 10 300 python bench.py --workload c5 --steps 3 --no-cpu-baseline 2>/dev/null | python -c "$show" "$(basename $lib)" || exit 1
 done
