@@ -253,27 +253,39 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
     return have;
   };
 
-  // copy the level strings of step s of the rows in `rows` into the wave's LDS (lane = one dword of one row)
+  // copy the level strings of step s of the rows in `rows` into the wave's LDS (lane = one dword of one row).  All
+  // rows' dwords are REQUESTED first (unconditionally; the lanes of a row that is not wanted read a wanted row's string)
+  // and stored afterwards: with a load and its store inside a per-row branch the rows' round trips came one after
+  // the other -- four per step and batch for 256-byte strings, at 1.5 waves per SIMD.  The level's row comes from the
+  // batch's heads (first row and depth are kept there), for every step.
   auto stage_strings = [&](int ib, uint32_t rows, int s) __attribute__((always_inline)) {
     constexpr int kDw = 16 * K;              // dwords per string row
     constexpr int kPer = kWave / kDw > 0 ? kWave / kDw : 1;  // rows per pass (K = 1: 4, K = 2: 2, K >= 4: 1)
     constexpr int kPass = kDw > kWave ? kDw / kWave : 1;     // passes per row (K = 8: 2)
-    for (int r0 = 0; r0 < kBatch; r0 += kPer) {
-      const int r = r0 + (kPer > 1 ? lane / kDw : 0);
-      const bool on = r < kBatch && ((rows >> r) & 1u);
-      if (!__any(on)) continue;
+    constexpr int kGroups = (kBatch + kPer - 1) / kPer;
+    if (!rows) return;
+    const int r_any = __builtin_ctz(rows);  // a row whose head is valid: what the lanes of unwanted rows read
+    uint32_t v[kGroups][kPass];
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) {
+      const int r_mine = g * kPer + (kPer > 1 ? lane / kDw : 0);
+      const int r = (r_mine < kBatch && ((rows >> r_mine) & 1u)) ? r_mine : r_any;
+      const uint32_t* rec = head + r * 3 * kHeadDwords;
+      const int lrow = static_cast<int>(rec[NB + 3]) + max(0, min(s, static_cast<int>(rec[NB + 2]) - 1));
 #pragma unroll
       for (int q = 0; q < kPass; ++q) {
         const int dw = (kPer > 1 ? lane % kDw : lane) + q * kWave;
-        if (on) {
-          int lrow;
-          if (s <= 3) lrow = static_cast<int>(head[(r * 3 + (s - 1)) * kHeadDwords + NB + 1]);
-          else {
-            const int i = ib + r;
-            lrow = lfirst[i] + max(0, min(s, lnlev[i] - 1));
-          }
-          const uint32_t v = reinterpret_cast<const uint32_t*>(lcodes + static_cast<size_t>(lrow) * kRow)[dw];
-          reinterpret_cast<uint32_t*>(lstr + r * kRow)[dw] = v;
+        v[g][q] = reinterpret_cast<const uint32_t*>(lcodes + static_cast<size_t>(lrow) * kRow)[dw];
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) {
+      const int r = g * kPer + (kPer > 1 ? lane / kDw : 0);
+      if (r < kBatch && ((rows >> r) & 1u)) {
+#pragma unroll
+        for (int q = 0; q < kPass; ++q) {
+          const int dw = (kPer > 1 ? lane % kDw : lane) + q * kWave;
+          reinterpret_cast<uint32_t*>(lstr + r * kRow)[dw] = v[g][q];
         }
       }
     }
