@@ -376,8 +376,10 @@ int launch_raw(const nsm_set_table* l, const nsm_set_table* r, double threshold,
     // + ordering ms): for W = 16 the class of two 12-id sets -- it turns weak below ~0.45, where the matrix kernel
     // takes 3.5 ms at 0.4 and 5.9 ms at 0.35 against the index kernel's flat 0.7, and small vocabularies lose at most
     // 7 % (500 ids at 0.4: 1.04 vs 0.97 ms); from 0.45 up the signature kernel wins on small vocabularies (0.50 vs
-    // 0.98 ms) and from 0.55 up everywhere (C4 at 0.8: 38 vs 127 ms).  W = 32 keeps the mid-size class (not swept).
-    constexpr int kDecider = W == 16 ? 12 : W / 2;
+    // 0.98 ms) and from 0.55 up everywhere (C4 at 0.8: 38 vs 127 ms).  W = 32 (Poisson(16) ids): the class of two
+    // 24-id sets is weak up to ~0.65; there the index wins 6 - 30x on 2^17 ids (0.5: 1.1 vs 15.2 ms, 0.6: 1.1 vs 6.5)
+    // and loses at most 39 % on 500 ids (0.6: 1.75 vs 1.26 ms).
+    constexpr int kDecider = 3 * W / 4;
     const bool weak_mid = (p.weak[kDecider] >> kDecider) & 1ull;
     // (the index kernel addresses the left ids with 32-bit byte offsets)
     const bool use_index = threshold > 0.0 && !(flags & NSM_FLAG_NO_INDEX) && static_cast<long long>(l->n) * W * 4 < (1ll << 32) &&
