@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: pair-comparisons/sec of the all-pairs match loop on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c2low|c3|c4|c5|term] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload all|c2|c2low|c3|c4|c5|term] [--no-cpu-baseline]
 
 N > 1 is launched by the driver as
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -34,7 +34,12 @@ The JSON line carries, besides the driver's contract fields:
                 compulsory byte counts, and the profile's stamp (git head, hash of csrc/ -- a stale profile shows).
   exhaustive    the same grid with the exact prune disabled (every pair's full comparison evaluated)
   cpu_baseline  the oracle's restatement of the reference's loop, 1 core, bounded sample
-  c4            (N > 1 only) BASELINE configs[3], 1M x 1M strong-scaled over the ranks, after the headline
+  c2low c3 c4 c5 term   (default `--workload all`) every other BASELINE config and the reference's default
+                configuration, timed in the SAME invocation after the headline, each under the same contract
+                (W warm-up steps, K timed steps between fences; c5: min(K, 5) steps of six 500k x 500k grids) with
+                its own value / ms_per_step / steps / kernel_ms / roofline / exhaustive / cpu_baseline.  N = 1 runs
+                all five; N > 1 runs the two configs BASELINE.json quotes on 8 GPUs (c4, c5: left rows divided
+                over the ranks, "strong").  `--workload <one>` times that workload alone.
 """
 import argparse
 import hashlib
@@ -64,7 +69,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=("c2", "c2low", "c3", "c4", "c5", "term"), default="c2")
+    ap.add_argument("--workload", choices=("all", "c2", "c2low", "c3", "c4", "c5", "term"), default="all",
+                    help="all = the c2 headline line with every other workload attached as a sub-record")
     ap.add_argument("--rows", type=int, default=0, help="override rows per side per GPU (debug)")
     ap.add_argument("--right-rows", type=int, default=0, help="override the right side's rows (debug)")
     ap.add_argument("--threshold", type=float, default=None, help="override the workload's threshold (debug)")
@@ -77,7 +83,7 @@ def parse_args():
     ap.add_argument("--allow-gloo", action="store_true",
                     help="if RCCL cannot be brought up on every rank, run the exchange staged through host memory "
                          "instead of exiting non-zero (the JSON's config.exchange says which one ran)")
-    ap.add_argument("--no-c4", action="store_true", help="N > 1: skip the extra configs[3] (1M x 1M strong) run")
+    ap.add_argument("--no-c4", action="store_true", help="(kept for old command lines) same as --workload c2")
     return ap.parse_args()
 
 
@@ -96,10 +102,14 @@ class Workload:
         self.lib = _lib.load()
         self.flag_prune = _lib.FLAG_PRUNE
         self.scaling = "weak"
+        lo_global = None
         if name == "c4":  # configs[3]: the C2 generator at 1M x 1M, threshold 0.8, left rows divided over the ranks
+            from napkon_string_matching_amd import distributed
+
             total = rows or 1_000_000
             right_rows = right_rows or total
-            rows = -(-total // world)
+            lo_global, hi_global = distributed.shard_bounds(total, rank, world)
+            rows = hi_global - lo_global
             threshold = 0.8 if threshold is None else threshold
             self.scaling = "strong"
         if name == "c2low":  # configs[1]'s grid at the API's default score_threshold (types/comparable_data.py:74)
@@ -108,19 +118,24 @@ class Workload:
             n = rows or 50_000
             m = right_rows or rows or 50_000
             self.threshold = 0.5 if threshold is None else threshold
-            # global left corpus = world * n rows; this rank scores rows [rank*n, (rank+1)*n)
             kw = {"id_range": id_range} if id_range else {}
-            left = synthetic.token_sets(n, 1234 + 1000 * rank, **kw)
             right = synthetic.token_sets(m, 5678, **kw)
-            if rank == 0:
-                right_planted = synthetic.plant_near_duplicate_sets(left, right, 5679, **kw)
+            if name == "c4":
+                # ONE global left corpus (seeded: every rank generates it and keeps its block), so that the hits of
+                # the ranks together are the hits of the 1-rank run
+                whole = synthetic.token_sets(total, 1234, **kw)
+                left = np.ascontiguousarray(whole[lo_global:lo_global + n])
+                right_planted = synthetic.plant_near_duplicate_sets(whole, right, 5679, **kw) if rank == 0 else None
+                del whole
             else:
-                right_planted = None
+                # weak scaling: global left corpus = world * n rows; this rank scores rows [rank*n, (rank+1)*n)
+                left = synthetic.token_sets(n, 1234 + 1000 * rank, **kw)
+                right_planted = synthetic.plant_near_duplicate_sets(left, right, 5679, **kw) if rank == 0 else None
             self.host = (left, right, right_planted)
             self.left_np = left
             right = comm.broadcast_numpy(right_planted, right)
             self.right_np = right
-            orig = np.arange(n, dtype=np.int32) + rank * n
+            orig = np.arange(n, dtype=np.int32) + (rank * n if lo_global is None else lo_global)
             t_enc = time.perf_counter()
             self.left = tables.SetTable.from_padded(left, "left", device, orig=orig)
             self.right = tables.SetTable.from_padded(right, "right", device)
@@ -278,6 +293,16 @@ class Comm:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def sum_int(self, v):
+        """Sum of a host integer over the ranks (gloo control plane)."""
+        if self.dist is None:
+            return int(v)
+        import torch
+
+        t = torch.tensor([int(v)], dtype=torch.int64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return int(t.item())
+
     def broadcast_numpy(self, array, like):
         """Rank 0's array on every rank (the replicated right side)."""
         import torch
@@ -365,6 +390,9 @@ def valu_roofline(profile_name, kernel_match, kernel_label, kernel_ms, launches_
         "matches_source": prof.get("csrc_sha256_16") == csrc_hash(),
         "kernel_us_under_pmc": entry.get("mean_us_under_pmc"),
     }
+    # the kernel sources changed after the counters were collected: the instruction count may describe a kernel
+    # that no longer exists (tests/test_gpu_bench.py requires a fresh profile for the default run)
+    roof["stale"] = not roof["profile"]["matches_source"]
     return roof
 
 
@@ -414,7 +442,7 @@ def cpu_baseline(work, budget_pairs):
     }
 
 
-def run_c5(args, comm, device):
+def run_c5(args, comm, device, steps=None, warmup=None, cpu=True, sub=False):
     """BASELINE configs[4]: three hap / pop / suep shaped cohorts, levels mode (compare_terms), categories
     filtered, intersection_vs_union then fuzzy_match for every cohort pair.  One step = the six grids.
     The left rows of every cohort pair are divided over the ranks (total work fixed: "strong")."""
@@ -423,9 +451,12 @@ def run_c5(args, comm, device):
 
     from napkon_string_matching_amd import _lib, distributed, grid, synthetic, tables
     rank, world = comm.rank, comm.world
+    steps = args.steps if steps is None else steps
+    warmup = max(1, args.warmup if warmup is None else warmup)
     lib = _lib.load()
     rows = args.rows or 500_000
-    threshold = 0.7 if args.threshold is None else args.threshold  # max(cache 0.5, score 0.7), config.yml:11-12
+    # max(cache 0.5, score 0.7), config.yml:11-12; as a sub-record of the default run a --threshold meant for c2 is ignored
+    threshold = 0.7 if (args.threshold is None or sub) else args.threshold
     mode = _lib.CAT_INTERSECT_OR_BOTH_EMPTY
     names = ("hap", "pop", "suep")
     cohorts = {}
@@ -502,11 +533,11 @@ def run_c5(args, comm, device):
         comm.barrier()
         torch.cuda.synchronize(device)
 
-    for _ in range(max(1, args.warmup)):
+    for _ in range(warmup):
         step()
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     fence()
     dt = comm.max_seconds(time.perf_counter() - t0)
@@ -529,7 +560,7 @@ def run_c5(args, comm, device):
         torch.cuda.synchronize(device)
         return ev0.elapsed_time(ev1) / reps
 
-    reps = max(2, min(args.steps, 5))
+    reps = max(2, min(steps, 5))
     ms_indel, ms_jac = kernel_ms("indel", reps), kernel_ms("jaccard", reps)
     pairs_per_step = 2 * len(pairs) * rows * rows  # both score functions over every cohort pair
     local_pairs = len(pairs) * (hi - lo) * rows    # pairs one fuzzy pass of this rank scores
@@ -537,12 +568,12 @@ def run_c5(args, comm, device):
     str_bytes = sum(t.nbytes() for g in grids if g[0] == "indel" for t in (g[1][1], g[1][3]))
     result = {
         "metric": "pair-comparisons/sec (whole node), N x M all-pairs",
-        "value": pairs_per_step * args.steps / dt,
+        "value": pairs_per_step * steps / dt,
         "unit": "pair-comparisons/s",
         "n_gpus": world,
-        "steps": args.steps,
-        "warmup": max(1, args.warmup),
-        "ms_per_step": dt / args.steps * 1e3,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": dt / steps * 1e3,
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -555,8 +586,10 @@ def run_c5(args, comm, device):
             "threshold": threshold,
             "pairs_per_step": pairs_per_step,
             "hits_per_grid_this_rank": counts,
+            "hits_per_grid_all_ranks": [comm.sum_int(c) for c in counts],
             "sharding": f"left rows of every cohort pair block-sharded over {world} rank(s), right replicated, hits all-gathered",
             "exchange": comm.exchange,
+            "rccl_ranks_seen": comm.rccl_ranks,
             "encode_and_h2d_seconds_once": round(t_encode, 2),
             "level_string_generation_seconds_once": round(t_generate, 2),
             "fuzzy_grids_ms_per_step": ms_indel,
@@ -564,9 +597,9 @@ def run_c5(args, comm, device):
         },
         "roofline": valu_roofline("c5", "indel_levels_park_kernel<1>", "indel_levels_park_kernel<1> (3 launches per step)",
                                   ms_indel, len(pairs), local_pairs // len(pairs) * bytes_per_pair, str_bytes // len(pairs),
-                                  default_shape=not args.rows and args.threshold is None and world == 1),
+                                  default_shape=not args.rows and (args.threshold is None or sub) and world == 1),
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and cpu and not args.no_cpu_baseline:
         from oracle import compare as oc
         from oracle import score_functions as osf
 
@@ -591,7 +624,8 @@ def run_c5(args, comm, device):
     return result
 
 
-def run_raw(args, comm, device, name, rows=0, right_rows=0, threshold=None, steps=None, warmup=None, extras=True):
+def run_raw(args, comm, device, name, rows=0, right_rows=0, threshold=None, steps=None, warmup=None, extras=True,
+            cpu_scale=1.0):
     """One RAW-mode / term workload under the contract: W warm-up steps, K timed steps between
     barrier + synchronize fences, MAX over the ranks.  Returns the JSON object."""
     import torch
@@ -678,7 +712,7 @@ def run_raw(args, comm, device, name, rows=0, right_rows=0, threshold=None, step
     n_hits = int(buf.count.item())
     if n_hits > buf.capacity:
         raise SystemExit(f"hit buffer overflow ({n_hits} > {buf.capacity}); raise --capacity")
-    pairs_per_step = work.n * work.m * world
+    pairs_per_step = comm.sum_int(work.n) * work.m  # (the last shard of a strong-scaled grid may be shorter)
     value = pairs_per_step * steps / dt
 
     # ---- per-kernel duration of the dominant kernel, HIP events on the launch stream
@@ -717,6 +751,7 @@ def run_raw(args, comm, device, name, rows=0, right_rows=0, threshold=None, step
             "threshold": work.threshold,
             "pairs_per_step": pairs_per_step,
             "hits_per_rank": n_hits,
+            "hits_all_ranks": comm.sum_int(n_hits),
             "sharding": f"left rows block-sharded over {world} rank(s), right replicated, hits all-gathered",
             "exchange": comm.exchange,
             "rccl_ranks_seen": comm.rccl_ranks,
@@ -743,7 +778,8 @@ def run_raw(args, comm, device, name, rows=0, right_rows=0, threshold=None, step
             "lds_busy_frac": ex_roof.get("lds_busy_frac"),
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(work, {"c3": 80_000, "term": 360_000}.get(work.name, 20_000_000))
+        budget = {"c3": 80_000, "term": 360_000}.get(work.name, 20_000_000)
+        result["cpu_baseline"] = cpu_baseline(work, int(budget * cpu_scale))
     return result
 
 
@@ -766,17 +802,43 @@ def main():
     comm = Comm(args, rank, world, device)
     assert comm.world == args.gpus
 
+    def release():
+        import gc
+
+        gc.collect()
+        torch.cuda.empty_cache()
+
     if args.workload == "c5":
         result = run_c5(args, comm, device)
-    else:
+    elif args.workload != "all":
         result = run_raw(args, comm, device, args.workload, args.rows, args.right_rows, args.threshold)
-        if world > 1 and args.workload == "c2" and not args.no_c4 and not args.rows:
-            # the SCALE record also covers BASELINE configs[3]: 1M x 1M, threshold 0.8, the left rows divided
-            # over the ranks ("strong"); a short run, attached beside the headline
-            c4 = run_raw(args, comm, device, "c4", steps=max(2, min(args.steps, 5)), warmup=1, extras=False)
-            result["c4"] = {k: c4[k] for k in ("value", "unit", "ms_per_step", "steps", "scaling")}
-            result["c4"].update({"workload": c4["config"]["workload"], "hits_per_rank": c4["config"]["hits_per_rank"],
-                                 "exchange": c4["config"]["exchange"], "kernel_ms": c4["roofline"]["kernel_ms"]})
+    else:
+        # the headline (BASELINE configs[1]) ...
+        result = run_raw(args, comm, device, "c2", args.rows, args.right_rows, args.threshold)
+        # ... and every other workload under the same clock, attached as sub-records.  N > 1: the two configs
+        # BASELINE.json quotes on 8 GPUs (c4, c5), left rows divided over the ranks.
+        names = () if args.no_c4 else (("c2low", "c3", "c4", "c5", "term") if world == 1 else ("c4", "c5"))
+        t_all = time.perf_counter()
+        for name in names:
+            release()
+            t_sub = time.perf_counter()
+            if name == "c5":
+                sub = run_c5(args, comm, device, steps=max(1, min(args.steps, 5)), warmup=1, sub=True)
+            else:
+                # c2low / c4 share c2's CPU restatement (same function, same corpus generator): a short sample
+                sub = run_raw(args, comm, device, name, args.rows, 0 if name == "c4" else args.right_rows,
+                              args.threshold if name == "c2" else None, extras=world == 1,
+                              cpu_scale=0.25 if name in ("c2low", "c4") else 1.0)
+            rec = {k: sub[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "scaling", "dtype", "config",
+                                       "roofline", "exhaustive", "cpu_baseline") if k in sub}
+            rec["workload"] = sub["config"]["workload"]
+            rec["kernel_ms"] = sub["roofline"]["kernel_ms"]
+            rec["wall_seconds_incl_setup"] = round(time.perf_counter() - t_sub, 1)
+            result[name] = rec
+        if names:
+            result["sub_records_wall_seconds"] = round(time.perf_counter() - t_all, 1)
+    if world > 1 and comm.dev_group is not None:
+        assert comm.rccl_ranks == world, f"RCCL saw {comm.rccl_ranks} ranks of {world}"
     if rank == 0:
         print(json.dumps(result))
     comm.close()

@@ -193,11 +193,12 @@ int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_table* left
  *   They SORT (stable: ties stay in the caller's order), so the grids never see an unsorted table.
  *   They synchronise `stream` before returning (row count and validation verdict live on the device) and
  *   allocate their scratch stream-ordered (hipMallocAsync / hipFreeAsync): nothing is kept after the call.
- *   Data errors (row wider than the table, duplicate id with NSM_BUILD_VALIDATE, code unit >= alphabet,
+ *   Data errors (row wider than the table, duplicate id in a LEVELS row, code unit >= alphabet,
  *   category bit 63 in use where "both empty" must become a category) return NSM_E_BADARG.
  */
 #define NSM_BUILD_PARTITION 1u /* levels tables: one row per (item, category), rows grouped by category */
-#define NSM_BUILD_VALIDATE 2u  /* set tables: check that no id occurs twice in a row (O(width^2) per row) */
+#define NSM_BUILD_VALIDATE 2u  /* (ABI v2 callers; no effect since v3: RAW rows always drop repeated ids -- they are sets --
+                                  and a repeated id in a levels row is always NSM_E_BADARG) */
 #define NSM_BUILD_SORT 4u      /* string tables: sort by length descending and fill len_start (RAW grid);
                                   without it rows stay in input order (levels mode: items index them) */
 

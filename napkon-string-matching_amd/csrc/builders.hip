@@ -185,22 +185,30 @@ __global__ void set_rows_kernel(const int32_t* __restrict__ ids_in, int n, int w
   if (i >= n) return;
   const int32_t* src = ids_in + static_cast<size_t>(i) * width_in;
   int32_t* dst = ids_tmp + static_cast<size_t>(i) * width;
+  // The operand is a SET (the reference builds set(...) per pair, compare/score_functions.py:10-11): an id that
+  // occurs twice counts once.  RAW rows drop the repeats here; a levels row cannot (its prefix lengths count the
+  // caller's slots), so there a repeat is a data error -- always checked: a table with a repeated id would
+  // over-count |A n B| in the position matrix and in the inverted index (round-2 advice; `validate` is kept in the
+  // signature for ABI v2 callers and no longer changes anything).
+  (void)validate;
   int cnt = 0;
+  bool too_wide = false;
   for (int k = 0; k < width_in; ++k) {
     const int32_t v = src[k];
-    if (v >= 0) {
-      if (cnt < width) dst[cnt] = v;
-      ++cnt;
+    if (v < 0) continue;
+    bool seen = false;
+    for (int b = 0; b < min(cnt, width); ++b) seen = seen || dst[b] == v;
+    if (seen) {
+      if (nlev_in) atomicMax(&st->err, static_cast<int>(kErrDuplicateId));
+      else continue;
     }
+    if (cnt < width) dst[cnt] = v;
+    else too_wide = true;
+    ++cnt;
   }
-  if (cnt > width) {
+  if (too_wide) {
     atomicMax(&st->err, static_cast<int>(kErrRowTooWide));
     cnt = width;
-  }
-  if (validate) {
-    for (int a = 1; a < cnt; ++a)
-      for (int b = 0; b < a; ++b)
-        if (dst[a] == dst[b]) atomicMax(&st->err, static_cast<int>(kErrDuplicateId));
   }
   if (nlev_in) {
     const int L = nlev_in[i];
@@ -248,7 +256,7 @@ __global__ void set_gather_kernel(const int32_t* __restrict__ perm, const int32_
     for (int l = 0; l < max_levels; ++l) po[l] = pl[min(l, max(L, 1) - 1)];  // levels past the last repeat it
     const uint64_t c = cat ? cat[i] : 0ull;
     if (cat_out) cat_out[r] = c;
-    const int plen1 = pl[min(1, max(L, 1) - 1)];  // the set every step of compare_terms contains
+    const int plen1 = pl[min(min(1, max_levels - 1), max(L, 1) - 1)];  // the set every step of compare_terms contains
     const uint64_t sl1 = signature_word(src, min(plen1, cnt), 0x9E3779B1u);
     uint32_t* f = filt + static_cast<size_t>(r) * 8;
     f[0] = static_cast<uint32_t>(s1);

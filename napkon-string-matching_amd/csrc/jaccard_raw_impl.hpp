@@ -36,17 +36,18 @@ struct JacRawScalars {
   unsigned long long weak[W + 1];  // weak[|A|] bit |B|: the signature bound rarely fails for these sizes
 };
 
-// Inverted-index kernel (jaccard_raw_index.hip): slots of a wavefront's hash table; a tile holding more than 3/4
-// of that many ids is "dense" and is scored by the matrix kernel instead (launched with only_dense).
+// Inverted-index kernel (jaccard_raw_index.hip): slots of a block's open-addressing hash table.  A tile holding more
+// than 3/4 of that many ids is "dense" and is indexed in TWO passes of 32 lanes each (n_pass in the kernel): half a
+// tile holds at most 32 W ids, which never fills the table -- the insertion loop cannot wrap around a full table.
 template <int W>
 constexpr int index_slots() { return W == 16 ? 1024 : 2048; }
+static_assert(32 * 16 <= index_slots<16>() && 32 * 32 <= index_slots<32>(), "half a tile must fit the hash table");
 
 template <int W>
-__device__ __forceinline__ bool tile_is_dense(int nrj) {  // wave-uniform
-  int total = nrj;  // wave sum of the set sizes
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) total += __shfl_xor(total, off);
-  return total > index_slots<W>() * 3 / 4;
+__device__ __forceinline__ bool tile_is_dense(int nrj) {  // wave-uniform; all 64 lanes enabled
+  // wave sum of the set sizes on DPP (row sums) + v_readlane: a scalar, no ds_bpermute round trips
+  const uint32_t total = wave_reduce_u32(static_cast<uint32_t>(nrj), [](uint32_t x, uint32_t y) { return x + y; });
+  return static_cast<int>(total) > index_slots<W>() * 3 / 4;
 }
 
 template <int W>

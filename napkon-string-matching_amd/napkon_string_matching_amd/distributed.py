@@ -5,8 +5,8 @@ The grid shards naturally -- every pair's score depends on item i and item j onl
 rows are split into contiguous blocks, the right side is replicated and there is no collective on
 the data path.  The only exchange is at the end: an all-gatherv of the above-threshold
 ``(score, i, j)`` records.  RCCL has no native gatherv: the hit buffer carries its counter in a trailing
-record, so ONE all-gather of the max-padded storage moves records and counts (``all_gather_storage`` --
-the same function ``bench.py`` measures).  Volumes are tiny next to xGMI bandwidth (16 B per hit).
+record, so ONE all-gather of the max-padded storage moves records and counts (``all_gather_storage``; ``bench.py``
+times that collective on the device-resident buffer, the product adds host-side packing around it).  Volumes are tiny next to xGMI bandwidth (16 B per hit).
 """
 from __future__ import annotations
 
@@ -32,6 +32,23 @@ def shard_bounds(n: int, rank: int, world_size: int) -> Tuple[int, int]:
     return lo, min(n, lo + per)
 
 
+def barrier() -> None:
+    """Barrier of the default process group; nothing without one."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def broadcast_object(obj, src: int = 0):
+    """``obj`` of rank ``src`` on every rank (host objects: verdicts, small texts)."""
+    import torch.distributed as dist
+
+    box = [obj]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
 def all_gather_storage(storage: torch.Tensor, out: Optional[torch.Tensor] = None, group=None, async_op: bool = False):
     """THE exchange step of a sharded grid: one all-gather of a hit buffer's ``storage`` -- ``capacity`` 16-byte
     ``(score f64, i i32, j i32)`` records followed by one record whose first 8 bytes are the hit counter
@@ -40,8 +57,13 @@ def all_gather_storage(storage: torch.Tensor, out: Optional[torch.Tensor] = None
 
     With an RCCL group the tensors stay on the device (``out``: ``[world][capacity + 1][2]`` on the same
     device, allocated when omitted); with gloo the buffer is staged through host memory.  Returns
-    ``(out, work)``; ``work`` is the handle of an ``async_op`` RCCL gather, else None.  ``bench.py`` and
-    ``ComparableData.gen_comparable`` both go through here."""
+    ``(out, work)``; ``work`` is the handle of an ``async_op`` RCCL gather, else None.
+
+    Both callers move the same wire format through this function, but they do not do the same work around it:
+    ``bench.py`` gathers the DEVICE-resident ``HitBuffer.storage`` at a fixed capacity, asynchronously, overlapped
+    with the next grid; ``ComparableData.gen_comparable`` (``all_gather_hits`` below) starts from hits it has already
+    filtered on the host (blacklist), agrees on a capacity with one MAX all-reduce, packs, copies to the device,
+    gathers and copies back.  The exchange cost bench.py reports is the collective's, not the product path's."""
     import torch.distributed as dist
 
     size = dist.get_world_size(group)

@@ -187,6 +187,25 @@ class _Categories:
 
 
 # =============================================================================== the class
+def _agree_on_rank0(flag: bool) -> bool:
+    """Rank 0's verdict on every rank (one tiny broadcast; a no-op without a process group)."""
+    rank, size = distributed.world()
+    if size == 1:
+        return bool(flag)
+    return bool(distributed.broadcast_object(bool(flag) if rank == 0 else None))
+
+
+def _read_cache_collectively(cache_file: Path) -> Comparable:
+    """The cached ``Comparable``: read by rank 0 and handed to the other ranks (their ``cache_dir`` need not
+    be the same file system)."""
+    rank, size = distributed.world()
+    if size == 1:
+        return Comparable.read_json(cache_file)
+    text = cache_file.read_text(encoding="utf-8") if rank == 0 else None
+    text = distributed.broadcast_object(text)
+    return Comparable(data=json.loads(text))
+
+
 class ComparableData:
     """A cohort's items as a pandas frame plus the ``compare`` machinery.
 
@@ -334,9 +353,14 @@ class ComparableData:
             cache_file = Path(cache_dir) / CACHE_FILE_PATTERN.format(
                 self._hash_compare_args(other, existing_mappings_whitelist, existing_mappings_blacklist,
                                         compare_column, first, kwargs))
-        if cache_file is not None and cache_file.exists():
+        # hit or miss is decided ONCE for all ranks of a sharded run (rank 0 looks, everybody follows): with a
+        # rank-local exists() the ranks can disagree -- a cache_dir that is not shared between nodes, or a repeated
+        # compare() where one rank looks before rank 0's rename has landed -- and the ranks that miss would then
+        # wait in gen_comparable's collectives for a rank that never comes
+        use_cache = cache_file is not None and _agree_on_rank0(cache_file.exists())
+        if use_cache:
             logger.info("using cached result")
-            result = Comparable.read_json(cache_file)
+            result = _read_cache_collectively(cache_file)
         else:
             if cache_file is None:
                 # the rows between `first` and `score_threshold` only ever fed the cache file: without
@@ -358,6 +382,8 @@ class ComparableData:
                 cache_file.parent.mkdir(parents=True, exist_ok=True)
                 logger.info("write cache to file")
                 result.write_json(cache_file)
+            if cache_file is not None:
+                distributed.barrier()  # nobody returns (and calls compare again) before the file is in place
         result = result[result.match_score >= score_threshold]
         logger.info("got %i filtered entries", len(result))
         result.sort_by_score()

@@ -357,6 +357,53 @@ def main():
     dump("c1_hap_pop_100.json", case)
     print("C1 hits:", len(case["expected"]["gen_comparable"]["index"]))
 
+    # -- 6. result consumers: Matcher._analyse (matcher.py:290-312) on results the reference computed ----------
+    # The Matcher module pulls in ingestion back ends that are absent offline (psycopg2, bs4, openpyxl): inert
+    # stand-ins, none of them is reached -- the object is built with __new__ and only `results` is set.
+    for name in ("psycopg2", "psycopg2.extras", "bs4", "openpyxl"):
+        try:
+            __import__(name)
+        except Exception:
+            sys.modules[name] = types.ModuleType(name)
+    from napkon_string_matching.matcher import Matcher
+    from napkon_string_matching.types.comparable import ComparisonResults
+
+    r6 = random.Random(66)
+
+    def with_gecco_variables(rows, every):
+        out = []
+        for k, row in enumerate(rows):
+            row = dict(row)
+            row["Variable"] = ("gec_" if k % every == 0 else "var_") + row["Identifier"].lower() + ("" if k % 5 else "_x")
+            if k % 4 == 3:  # several items share a variable name: nunique < number of rows
+                row["Variable"] = out[k - 1]["Variable"]
+            out.append(row)
+        return out
+
+    cohorts6 = {
+        "hap": with_gecco_variables(cohort(r6, "hap", 25, vocab=30, max_tokens=4), 3),
+        "pop": with_gecco_variables(cohort(r6, "pop", 30, vocab=30, max_tokens=4), 4),
+        "suep": with_gecco_variables(cohort(r6, "suep", 20, vocab=30, max_tokens=4), 1000003),  # one gec_ variable only
+    }
+    kw6 = dict(score_func="intersection_vs_union", compare_column="Tokens", score_threshold=0.25)
+    steps = [("hap", "pop", 0.25), ("hap", "suep", 0.25), ("pop", "suep", 0.25), ("pop", "hap", 1.1)]  # the last: no hit
+    results, expected_rows = {}, {}
+    for a, b, thr in steps:
+        with tempfile.TemporaryDirectory() as tmp:
+            comp = Questionnaire(pd.DataFrame(cohorts6[a])).compare(
+                Questionnaire(pd.DataFrame(cohorts6[b])), Mapping(data={}), Mapping(data={}), cache_dir=tmp, cached=False,
+                left_name=a, right_name=b, **{**kw6, "score_threshold": thr})
+        key = f"{a} vs {b}"
+        results[key] = comp
+        frame = comp.data
+        while not isinstance(frame, pd.DataFrame):
+            frame = frame._data
+        expected_rows[key] = len(frame)
+    matcher = Matcher.__new__(Matcher)
+    matcher.results = ComparisonResults(comp_dict=results)
+    dump("analyse.json", {"cohorts": cohorts6, "compare_kwargs": kw6, "steps": [list(s_) for s_ in steps],
+                          "rows": expected_rows, "analysis": matcher._analyse()})
+
 
 if __name__ == "__main__":
     main()

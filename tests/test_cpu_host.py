@@ -294,3 +294,57 @@ def test_comparable_frame_conveniences():
     comp.drop_superfluous_columns()
     assert "Extra" not in comp.dataframe().columns and "MatchScore" in comp.dataframe().columns
     assert list(comp.match_variable) == ["a", "b"] and list(comp.variable) == ["x", "y"]  # match_<col> is the LEFT side
+
+
+_CACHE_WORKER = r'''
+import os, sys
+sys.path.insert(0, {pkg!r})
+import pandas as pd
+import torch.distributed as dist
+from napkon_string_matching_amd.types.comparable import Comparable
+from napkon_string_matching_amd.types.comparable_data import CACHE_FILE_PATTERN, ComparableData
+from napkon_string_matching_amd.types.questionnaire import Questionnaire
+
+rank = int(os.environ["RANK"])
+dist.init_process_group("gloo", rank=rank, world_size=2)
+frame = lambda tag: pd.DataFrame({{"Identifier": [tag + "1", tag + "2"], "Sheet": ["s", "s"], "Category": [["c"], ["c"]],
+                                  "Variable": ["v1", "v2"], "Term": [["x"], ["y"]], "Tokens": [["a", "b"], ["c"]]}})
+left, right = Questionnaire(frame("l")), Questionnaire(frame("r"))
+kw = dict(score_func="intersection_vs_union", left_name="hap", right_name="pop", filter_categories=False)
+# every rank has its OWN cache directory (a cache_dir that is not shared between nodes); only rank 0's holds the file
+cache_dir = os.path.join({tmp!r}, "rank%d" % rank)
+os.makedirs(cache_dir, exist_ok=True)
+key = left._hash_compare_args(right, None, None, "Tokens", 0.2, kw)
+if rank == 0:
+    rows = pd.DataFrame({{"HapIdentifier": ["l1"], "PopIdentifier": ["r1"], "MatchScore": [0.5]}})
+    Comparable(rows, "Hap", "Pop").write_json(os.path.join(cache_dir, CACHE_FILE_PATTERN.format(key)))
+
+
+def must_not_run(*a, **k):
+    raise AssertionError("rank %d entered gen_comparable although rank 0 holds the cached result" % rank)
+
+
+ComparableData.gen_comparable = must_not_run
+got = left.compare(right, None, None, compare_column="Tokens", score_threshold=0.3, cache_threshold=0.2,
+                   cache_dir=cache_dir, **kw)
+assert len(got) == 1 and got.match_score.tolist() == [0.5] and got.left_name == "Hap", (rank, got)
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_compare_cache_decision_is_collective_gloo_world2(tmp_path):
+    """Round-2 advice: with a rank-local ``exists()`` a cache that only one rank can see sends the ranks down
+    different paths and the ones that miss hang in gen_comparable's collectives.  Rank 0 decides for everybody and
+    hands the cached rows to the ranks that cannot read the file."""
+    script = tmp_path / "cache_worker.py"
+    script.write_text(_CACHE_WORKER.format(pkg=str(ROOT / "napkon-string-matching_amd"), tmp=str(tmp_path)))
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=240)
+        assert p.returncode == 0, out.decode()

@@ -1,10 +1,13 @@
 """The reference-shaped host API (score_func plugins, ComparableData, Matcher) driven through the
 HIP path, against (a) the golden fixtures produced by the reference itself and (b) the oracle."""
+from pathlib import Path
+
 import numpy as np
 import pandas as pd
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
 
 
 def _check(case, fn, *args):
@@ -366,3 +369,69 @@ def test_sharded_compare_world2(golden, tmp_path):
         for rank in range(2):
             got = json.load(open(str(tmp_path / "out") + str(rank)))[func]
             assert got == want
+
+
+def test_integration_md_level2_stub():
+    """INTEGRATION.md's level-2 binding, executed AS WRITTEN (raw ctypes on the C ABI: nsm_build_set_table +
+    nsm_jaccard_levels_grid, nsm_build_str_table + nsm_build_level_items + nsm_indel_levels_grid; nothing of the
+    package's tables.py), against the oracle on a C5-shaped cohort pair with the list x list category predicate."""
+    import re
+
+    from napkon_string_matching_amd import _lib, synthetic
+    from oracle import native
+
+    text = (ROOT / "INTEGRATION.md").read_text(encoding="utf-8")
+    level2 = text[text.index("## Level 2"):text.index("Entry points and what they replace")]
+    blocks = re.findall(r"```python\n(.*?)```", level2, flags=re.S)
+    assert len(blocks) == 2 and "napkon_string_matching_amd" not in "".join(blocks)
+    ns = {}
+    exec(compile("\n".join(blocks).replace('"libnsm_hip.so"', repr(str(_lib.LIB_PATH))), "INTEGRATION.md", "exec"), ns)
+
+    hap = synthetic.c5_cohort(700, 21)
+    pop = synthetic.c5_cohort(900, 22, plant_from=hap)
+    mode = _lib.CAT_INTERSECT_OR_BOTH_EMPTY
+    hap["cat"][:5] = 0  # items without a category: "both empty" matches (types/comparable_data.py:467-470)
+    pop["cat"][:7] = 0
+    canon = lambda s, i, j: sorted(zip(s.tolist(), i.tolist(), j.tolist()), key=lambda h: (-h[0], h[1], h[2]))
+
+    # ---- intersection_vs_union
+    lt, keep_l = ns["build_side"](hap["ids"], hap["nlev"], hap["plen"], hap["cat"], 0)
+    rt, keep_r = ns["build_side"](pop["ids"], pop["nlev"], pop["plen"], pop["cat"], 1)
+    got = canon(*ns["score_grid"](lt, rt, 0.55))
+    ids = lambda c: [[[int(t[1:]) for t in level] for level in item] for item in synthetic.c5_level_token_lists(c)]
+    want = native.levels(False, ids(hap), ids(pop), 0.55, hap["cat"], pop["cat"], mode, cap=1 << 16)
+    assert got == want and len(want) > 5
+
+    # ---- fuzzy_match
+    sides = []
+    for c in (hap, pop):
+        codes, lengths, first, nlev = synthetic.c5_level_codes(c)
+        sides.append(ns["build_fuzzy_side"](codes, lengths, first, nlev, c["cat"], len(synthetic.C5_ALPHABET)))
+    got = canon(*ns["score_fuzzy_grid"](sides[0][0], sides[1][0], 0.6))
+    cps = lambda c: [[[ord(ch) for ch in " ".join(level)] for level in item] for item in synthetic.c5_level_token_lists(c)]
+    want = native.levels(True, cps(hap), cps(pop), 0.6, hap["cat"], pop["cat"], mode, cap=1 << 16)
+    assert got == want and len(want) > 5
+
+
+def test_analyse_golden(golden):
+    """Row f4: ``Matcher._analyse`` (matcher.py:290-312).  The fixture holds what the REFERENCE's ``_analyse`` returned
+    for results the reference's own ``compare`` produced (tests/golden/make_golden.py section 6: ``gec_``-prefixed
+    variables on both sides, shared variable names, a cohort pair without hits); the package must return the same
+    strings from the results its GPU path computes on the same cohorts."""
+    from napkon_string_matching_amd.matcher import Matcher
+    from napkon_string_matching_amd.types.comparable import ComparisonResults
+    from napkon_string_matching_amd.types.questionnaire import Questionnaire
+
+    case = golden("analyse.json")
+    results = {}
+    for a, b, thr in case["steps"]:
+        left, right = Questionnaire(pd.DataFrame(case["cohorts"][a])), Questionnaire(pd.DataFrame(case["cohorts"][b]))
+        comp = left.compare(right, None, None, left_name=a, right_name=b, cached=False,
+                            **{**case["compare_kwargs"], "score_threshold": thr})
+        results[f"{a} vs {b}"] = comp
+        assert len(comp) == case["rows"][f"{a} vs {b}"]
+    m = Matcher(None, {"matching": case["compare_kwargs"]})
+    m.results = ComparisonResults(results)
+    got = m._analyse()
+    assert got == case["analysis"] and "pop vs hap" not in got  # an empty result is skipped (:299-300)
+    assert list(got) == list(case["analysis"])  # same order as the results were stored

@@ -16,7 +16,7 @@ CONTRACT = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 
 
 def _line(cmd):
-    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -41,6 +41,7 @@ def test_bench_line(workload):
     rows = {"c2": "8000", "c2low": "8000", "c3": "8000", "c4": "60000", "c5": "6000", "term": "3000"}[workload]
     d = _line([sys.executable, "bench.py", "--workload", workload, "--rows", rows, "--steps", "2", "--warmup", "1"])
     assert all(k in d for k in CONTRACT), sorted(d)
+    assert not any(k in d for k in ("c2low", "c3", "c4", "c5", "term"))  # one workload alone: no sub-records
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["higher_is_better"] is True
     assert d["unit"] == "pair-comparisons/s" and d["data"] == "synthetic" and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"] and "limiter" not in d
@@ -52,10 +53,25 @@ def test_bench_line(workload):
 
 def test_bench_default_roofline_is_a_fraction():
     """The default invocation's roofline is a fraction of a bound the kernel can approach: in (0, 1], backed by
-    the committed counter profile (round-1 verdict: 91.6 of HBM peak is not a roofline)."""
-    d = _line([sys.executable, "bench.py", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"])
+    the committed counter profile (round-1 verdict: 91.6 of HBM peak is not a roofline).  The default invocation
+    also carries every other BASELINE config and the reference's default configuration as sub-records, each under
+    the same contract (round-2 verdict: only configs[1] was driver-timed)."""
+    d = _line([sys.executable, "bench.py", "--steps", "5", "--warmup", "2"])
     _check_roofline(d["roofline"], need_frac=True)
+    assert d["roofline"]["stale"] == (not d["roofline"]["profile"]["matches_source"])
     assert d["exhaustive"]["valu_issue_frac"] is None or 0.0 < d["exhaustive"]["valu_issue_frac"] <= 1.0
+    assert "C2" in d["config"]["workload"] and d["cpu_baseline"]["value"] > 0
+    for name, steps in (("c2low", 5), ("c3", 5), ("c4", 5), ("c5", 5), ("term", 5)):
+        sub = d[name]
+        assert sub["steps"] == steps and sub["value"] > 0 and sub["ms_per_step"] > 0 and sub["kernel_ms"] > 0, name
+        assert sub["unit"] == "pair-comparisons/s" and name.upper() in sub["workload"].upper()
+        _check_roofline(sub["roofline"], need_frac=True)
+        assert sub["cpu_baseline"]["kind"] == "port" and sub["cpu_baseline"]["value"] > 0
+        if name != "c5":
+            assert sub["exhaustive"]["ms_per_step"] >= 0.9 * sub["ms_per_step"]
+        # the timed region fits the wall time the record reports for itself
+        assert sub["steps"] * sub["ms_per_step"] * 1e-3 < sub["wall_seconds_incl_setup"]
+    assert d["sub_records_wall_seconds"] < 420
 
 
 def test_bench_rccl_failure_is_loud():
@@ -90,3 +106,16 @@ def test_bench_two_ranks_gloo():
                "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1",
                "--rows", "6000", "--dist-backend", "gloo"])
     assert d["n_gpus"] == 2 and d["config"]["pairs_per_step"] == 2 * 6000 * 6000 and "cpu_baseline" not in d
+    # N > 1 carries the two configs BASELINE.json quotes on 8 GPUs, left rows divided over the ranks
+    assert set(("c4", "c5")) <= set(d) and "c3" not in d and "term" not in d
+    for name in ("c4", "c5"):
+        sub = d[name]
+        assert sub["scaling"] == "strong" and sub["value"] > 0 and sub["config"]["exchange"].startswith("gloo")
+        assert "rccl_ranks_seen" in sub["config"] and "cpu_baseline" not in sub
+    # the ranks' hit counts add up to what ONE rank finds on the same (seeded) grid
+    one = _line([sys.executable, "bench.py", "--workload", "c4", "--rows", "6000", "--steps", "1", "--warmup", "1",
+                 "--no-cpu-baseline"])
+    assert d["c4"]["config"]["hits_all_ranks"] == one["config"]["hits_per_rank"] > 0
+    one = _line([sys.executable, "bench.py", "--workload", "c5", "--rows", "6000", "--steps", "1", "--warmup", "1",
+                 "--no-cpu-baseline"])
+    assert d["c5"]["config"]["hits_per_grid_all_ranks"] == one["config"]["hits_per_grid_this_rank"]

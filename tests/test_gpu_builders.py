@@ -139,11 +139,23 @@ def test_builder_rejects_bad_rows(dev):
     st = _lib.NsmSetTable(cols["ids"].data_ptr(), cols["cnt"].data_ptr(), cols["sig"].data_ptr(), cols["sig2"].data_ptr(),
                           cols["orig"].data_ptr(), cols["size_start"].data_ptr(), None, None, None, None, None, None, n, width, 0)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    rc = lib.nsm_build_set_table(ids.data_ptr(), n, 4, 0, None, None, None, None, 0, _lib.BUILD_VALIDATE, ctypes.byref(st), stream)
+    # RAW rows are SETS (the reference builds set(...) per pair): a repeated id counts once, flag or no flag
+    for flags in (_lib.BUILD_VALIDATE, 0):
+        st.n = n
+        rc = lib.nsm_build_set_table(ids.data_ptr(), n, 4, 0, None, None, None, None, 0, flags, ctypes.byref(st), stream)
+        assert rc == 0 and st.n == 2
+        assert cols["cnt"].cpu().tolist() == [2, 1] and cols["orig"].cpu().tolist() == [0, 1]  # sorted by size, descending
+        assert cols["ids"].cpu()[0, :3].tolist() == [1, 2, -1]
+    # a levels row cannot drop a repeat (its prefix lengths count the caller's slots): data error, always
+    lev = dict(nlev=torch.ones(n, dtype=torch.int32, device=dev), plen=torch.tensor([[3], [1]], dtype=torch.uint8, device=dev),
+               nlev_o=torch.empty(n, dtype=torch.int32, device=dev), plen_o=torch.empty((n, 1), dtype=torch.uint8, device=dev),
+               filt=torch.empty((n, 8), dtype=torch.int32, device=dev))
+    st2 = _lib.NsmSetTable(cols["ids"].data_ptr(), cols["cnt"].data_ptr(), cols["sig"].data_ptr(), cols["sig2"].data_ptr(),
+                           cols["orig"].data_ptr(), cols["size_start"].data_ptr(), lev["nlev_o"].data_ptr(), lev["plen_o"].data_ptr(),
+                           None, lev["filt"].data_ptr(), None, None, n, width, 1)
+    rc = lib.nsm_build_set_table(ids.data_ptr(), n, 4, 0, lev["nlev"].data_ptr(), lev["plen"].data_ptr(), None, None, 0, 0,
+                                 ctypes.byref(st2), stream)
     assert rc == 10001 and b"duplicate id" in lib.nsm_last_error()
-    rc = lib.nsm_build_set_table(ids.data_ptr(), n, 4, 0, None, None, None, None, 0, 0, ctypes.byref(st), stream)
-    assert rc == 0 and st.n == 2
-    assert cols["cnt"].cpu().tolist() == [3, 1] and cols["orig"].cpu().tolist() == [0, 1]  # sorted by size, descending
     st.n = 1  # output columns too short
     rc = lib.nsm_build_set_table(ids.data_ptr(), n, 4, 0, None, None, None, None, 0, 0, ctypes.byref(st), stream)
     assert rc == 10001 and b"rows" in lib.nsm_last_error()

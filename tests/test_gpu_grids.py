@@ -59,7 +59,7 @@ def test_jaccard_raw_random(dev, width, kmax, vocab, prune):
 @pytest.mark.parametrize("width,kmax,vocab,n_left,n_right", [
     (16, 16, 60, 333, 517),         # tiny vocabulary: every pair is a candidate, the early tiles are dense
     (16, 10, 5000, 2100, 1700),     # sparse: most probes miss
-    (16, 16, 100000, 900, 2500),    # all rows full: every tile is dense (the matrix kernel takes them)
+    (16, 16, 100000, 900, 2500),    # all rows full: every tile is dense (indexed in two passes of 32 lanes)
     (32, 30, 700, 700, 900),
     (32, 12, 90, 300, 400),
 ])
