@@ -169,8 +169,8 @@ class Workload:
             li, ls, ri, rs = self.term_tables
             self.left, self.right = ls, rs
             self.term_structs = (li.struct(), ls.struct(), ri.struct(), rs.struct())
-            self.kernel = f"indel_levels_park_kernel<{ls.stride // 64}>"
-            self.kernel_match = f"indel_levels_park_kernel<{ls.stride // 64}>"
+            self.kernel = f"indel_levels_tile_kernel<{ls.stride // 64}>"
+            self.kernel_match = f"indel_levels_tile_kernel<{ls.stride // 64}>"
             self.kernel_match_exhaustive = f"indel_levels_kernel<{ls.stride // 64}>"
             self.dtype = "u64"
             lens = [len(s) for it in self.left_np for s in it[1:]]

@@ -148,6 +148,8 @@ typedef struct nsm_level_items {
 #define NSM_FLAG_INDEX 4u    /* nsm_jaccard_raw_grid: candidate generation by inverted index (chosen by itself at low
                                 thresholds, where the signature prune stops paying; this forces it) */
 #define NSM_FLAG_NO_INDEX 8u /* nsm_jaccard_raw_grid: never use the inverted index (A/B runs, tests) */
+#define NSM_FLAG_PARK 16u /* nsm_indel_levels_grid, strings beyond 64 code units: the round-2 kernel (one right tile per
+                             wavefront, block-shared park) instead of the shared-tile kernel; same hits, A/B runs and tests */
 #define NSM_FLAG_WAVE_WIDE 2u /* nsm_indel_levels_grid: score every step wave-wide (no block-cooperative
                                  parking of the surviving pairs); same hits, kept for A/B runs and tests */
 

@@ -286,6 +286,18 @@ __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
 }  // namespace nsm
 
 #include "indel_levels_park.hpp"
+#include "indel_levels_tile.hpp"
+
+#ifdef NSM_TILE_STATS
+// variant builds only: copy the tile kernel's work counters to `out[16]` and reset them (synchronises the device)
+extern "C" int nsm_debug_tile_stats(unsigned long long* out) {
+  unsigned long long zero[16] = {0};
+  hipDeviceSynchronize();
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(nsm::g_tile_stats), sizeof(zero));
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(nsm::g_tile_stats), zero, sizeof(zero));
+  return static_cast<int>(e);
+}
+#endif
 
 extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_table* left_strings,
                                      const nsm_level_items* right, const nsm_str_table* right_strings,
@@ -296,6 +308,9 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
     set_error("nsm_indel_levels_grid: null argument");
     return NSM_E_BADARG;
   }
+#ifdef NSM_DEFAULT_PARK  // A/B builds (tools/build_variant.sh): the round-2 kernel for multi-word strings
+  flags |= NSM_FLAG_PARK;
+#endif
   const int stride = left_strings->stride;
   if (stride != right_strings->stride || (stride != 64 && stride != 128 && stride != 256 && stride != 512)) {
     set_error("nsm_indel_levels_grid: stride %d/%d unsupported (both sides 64, 128, 256 or 512 code units)",
@@ -361,7 +376,91 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
                      left->first, left->nlev, left->orig, left->cat, left->seg_start, left_strings->codes,     \
                      left_strings->len, right->first, right->nlev, right->orig, right->cat, right->seg,         \
                      right_strings->codes, right_strings->len, hits, hit_count, p)
-  if (!(flags & NSM_FLAG_WAVE_WIDE)) {
+  if (!(flags & NSM_FLAG_WAVE_WIDE) && K > 1 && !(flags & NSM_FLAG_PARK)) {
+    // multi-word strings: shared-tile kernel (indel_levels_tile.hpp) -- the waves of a block share one right tile
+    // whose level strings stay resident in LDS, and divide the left rows
+    TileParams q;
+    q.n_left = left->n; q.n_right = right->n; q.cap = capacity;
+    q.n_tiles = n_tiles;
+    q.cat_mode = category_mode;
+    q.threshold = threshold;
+    q.use_hist = ((flags & NSM_FLAG_PRUNE) && left_strings->hist && right_strings->hist) ? 1 : 0;
+    q.pm_stride = (left_strings->alphabet + 1 + 7) / 8 * 8;
+#ifndef NSM_TILE_PARK_MAX
+#define NSM_TILE_PARK_MAX 24
+#endif
+    q.park_max = NSM_TILE_PARK_MAX;
+    q.park_slots = kTileBatch * q.park_max;  // a row parks at most once, <= park_max pairs; drained after every batch
+    const size_t tbl_bytes = static_cast<size_t>(q.pm_stride) * tile_words(K) * 8;
+    const size_t wave_bytes = (kTileTables * tbl_bytes + kTileBatch * 3 * kTileHead * 4 + 2 * kTileBatch * kWave * K +
+                               kTileBatch * 2 * 4 + static_cast<size_t>(q.park_slots) * 12 + 15) & ~static_cast<size_t>(15);
+    auto block_bytes = [&](int n_img) -> size_t {
+      const int n_hist = n_img > 3 ? n_img : 3;
+      return static_cast<size_t>(n_img) * 16 * K * kWave * 4 + static_cast<size_t>(n_hist) * (8 * kWave * 4 + kWave * 4) +
+             2 * kWave * 4 + 67 * 16;
+    };
+    // One block per CU (all 160 KB of its LDS): as many waves as fit beside the images, 16 at most.  Three resident
+    // images (the level strings of steps 1..3) when at least 12 waves fit with them, else two.
+#ifndef NSM_TILE_IMG
+#define NSM_TILE_IMG 0
+#endif
+#ifndef NSM_TILE_WAVES
+#define NSM_TILE_WAVES 0
+#endif
+    constexpr size_t kLdsCu = 160 * 1024;
+    auto waves_for = [&](int n_img) -> int {
+      const size_t b = block_bytes(n_img);
+      if (b + wave_bytes > kLdsCu) return 0;
+      const size_t w = (kLdsCu - b) / wave_bytes;
+      const size_t most = static_cast<size_t>(tile_max_waves(K));  // (the kernel's launch bound)
+      return static_cast<int>(w > most ? most : w);
+    };
+    // (term, 20k x 20k at 0.5: 12 waves with two images 98 ms, with three 90 ms -- items of 4+ levels read their step-3
+    // texts from global memory when only two steps are resident)
+    int n_img = NSM_TILE_IMG ? NSM_TILE_IMG
+                             : (waves_for(4) >= tile_max_waves(K) ? 4 : waves_for(3) >= (3 * tile_max_waves(K)) / 4 ? 3 : 2);
+    int tw = waves_for(n_img);
+    if (NSM_TILE_WAVES && tw > NSM_TILE_WAVES) tw = NSM_TILE_WAVES;
+    if (tw < 1) {
+      set_error("nsm_indel_levels_grid: alphabet %d at stride %d needs %zu bytes of LDS", left_strings->alphabet, stride,
+                block_bytes(n_img) + wave_bytes);
+      return NSM_E_UNSUPPORTED;
+    }
+    q.n_img = n_img;
+    // left slices: enough blocks to fill the chip a few times over, every wave of a block with a few batches of work
+    const long long rows_cat = left->seg ? (left->n + 31) / 32 : left->n;  // (rows a tile visits, roughly)
+#ifndef NSM_TILE_ROUNDS
+#define NSM_TILE_ROUNDS 10
+#endif
+    long long slices = (256ll * NSM_TILE_ROUNDS + n_tiles - 1) / n_tiles;
+    const long long max_slices = rows_cat / (static_cast<long long>(tw) * kTileBatch * 4) + 1;
+    if (slices > max_slices) slices = max_slices;
+    if (slices < 1) slices = 1;
+    if (slices > 4096) slices = 4096;
+    q.y_slices = static_cast<int>(slices);
+    q.rows_per_slice = static_cast<int>(((left->n + slices - 1) / slices + kTileBatch - 1) / kTileBatch * kTileBatch);
+    const size_t lds_tile = block_bytes(n_img) + static_cast<size_t>(tw) * wave_bytes;
+    const unsigned blocks = static_cast<unsigned>(8ll * ((n_tiles + 7) / 8) * slices);
+#define NSM_LAUNCH_TILE(KK)                                                                                        \
+  do {                                                                                                             \
+    static bool attr_set = false;                                                                                  \
+    if (!attr_set) {                                                                                               \
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&indel_levels_tile_kernel<KK>),       \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);            \
+      if (e != hipSuccess) return hip_status(e, "hipFuncSetAttribute(indel_levels_tile_kernel)");                  \
+      attr_set = true;                                                                                             \
+    }                                                                                                              \
+    hipLaunchKernelGGL((indel_levels_tile_kernel<KK>), dim3(blocks), dim3(tw * kWave), lds_tile,                   \
+                       static_cast<hipStream_t>(stream), left->first, left->nlev, left->orig, left->cat,           \
+                       left->seg_start, left_strings->codes, left_strings->len, left_strings->hist, right->first,  \
+                       right->nlev, right->orig, right->cat, right->seg, right_strings->codes, right_strings->len, \
+                       right_strings->hist, hits, hit_count, q);                                                   \
+  } while (0)
+    if (K == 2) NSM_LAUNCH_TILE(2);
+    else if (K == 4) NSM_LAUNCH_TILE(4);
+    else NSM_LAUNCH_TILE(8);
+#undef NSM_LAUNCH_TILE
+  } else if (!(flags & NSM_FLAG_WAVE_WIDE)) {
     // scan + park + dense finish (indel_levels_park.hpp)
     ParkParams q;
     q.n_left = left->n; q.n_right = right->n; q.cap = capacity;

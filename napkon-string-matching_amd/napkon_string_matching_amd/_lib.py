@@ -10,6 +10,7 @@ ABI_VERSION = 2
 FLAG_PRUNE = 1
 FLAG_WAVE_WIDE = 2  # nsm_indel_levels_grid without the block-cooperative parking (A/B runs, tests)
 FLAG_INDEX, FLAG_NO_INDEX = 4, 8  # nsm_jaccard_raw_grid: force / forbid the inverted-index kernel
+FLAG_PARK = 16  # nsm_indel_levels_grid, strings > 64 code units: the round-2 park kernel instead of the shared-tile kernel
 BUILD_PARTITION, BUILD_VALIDATE, BUILD_SORT = 1, 2, 4
 CAT_NONE, CAT_INTERSECT, CAT_INTERSECT_OR_BOTH_EMPTY = 0, 1, 2
 

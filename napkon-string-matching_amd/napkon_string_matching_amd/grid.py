@@ -166,12 +166,14 @@ def jaccard_levels_grid(
 def indel_levels_grid(
     left: LevelItems, left_strings: StrTable, right: LevelItems, right_strings: StrTable, threshold: float,
     category_mode: int = _lib.CAT_NONE, prune: bool = True, capacity: Optional[int] = None, wave_wide: bool = False,
+    park: bool = False,
 ) -> Hits:
     """``compare_terms`` with ``fuzzy_match`` over per-level strings.  ``wave_wide`` selects the kernel
-    without block-cooperative parking (same hits; A/B runs and tests)."""
+    without block-cooperative parking, ``park`` the round-2 kernel for multi-word strings (same hits; A/B runs
+    and tests)."""
     lib = _lib.load()
     li, ls, ri, rs = left.struct(), left_strings.struct(), right.struct(), right_strings.struct()
-    flags = (_lib.FLAG_PRUNE if prune else 0) | (_lib.FLAG_WAVE_WIDE if wave_wide else 0)
+    flags = (_lib.FLAG_PRUNE if prune else 0) | (_lib.FLAG_WAVE_WIDE if wave_wide else 0) | (_lib.FLAG_PARK if park else 0)
     if (left.seg is None) != (right.seg is None) or left.category_mode != right.category_mode:
         raise ValueError("both sides must be encoded alike: same category_mode and partition (tables.partition_allowed)")
     if left.category_mode is not None:  # the encoder may have rewritten the predicate (partition)

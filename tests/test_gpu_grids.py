@@ -464,3 +464,51 @@ def test_sort_hits_large(dev):
         order = np.lexsort((j, i, -score))
         assert np.array_equal(got.score, score[order])
         assert np.array_equal(got.i, i[order]) and np.array_equal(got.j, j[order])
+
+
+@pytest.mark.parametrize("entries,words,n_left,n_right,stride", [
+    ((2, 4), (1, 3), 150, 330, 128),    # 128-unit rows (K = 2): 16 waves per block
+    ((3, 5), (2, 5), 170, 300, 256),    # the reference's Term shape (K = 4)
+    ((3, 8), (2, 5), 120, 200, 256),    # items deeper than the resident images: levels read from global memory
+    ((4, 8), (3, 6), 70, 130, 512),     # 512-unit rows (K = 8), deep items
+])
+def test_indel_levels_term_like(dev, entries, words, n_left, n_right, stride):
+    """Multi-word level strings through the shared-tile kernel (round 3: all waves of a block share one right tile
+    whose level strings stay resident in LDS): suffix-nested Term-shaped items, several tiles with a partial last one,
+    thresholds from "everything survives every step" to "nearly nothing survives step 1", with and without a category
+    partition -- against the C oracle (O(nm) DP per level pair), the round-2 park kernel and the wave-wide kernel."""
+    from napkon_string_matching_amd import _lib, grid, synthetic, tables
+    from napkon_string_matching_amd.compare import score_functions as sf
+    from oracle import native
+
+    rng = random.Random(entries[1] * 100 + words[1])
+    lt_items = synthetic.term_cohort(n_left, 31, vocab=300, entries=entries, words=words)
+    rt_items = synthetic.term_cohort(n_right, 32, vocab=300, entries=entries, words=words, plant_from=lt_items,
+                                     plant_fraction=0.05)
+    ops = lambda items: [[sf.fuzzy_operand(lv) for lv in it] for it in synthetic.term_levels(items)]
+    left, right = ops(lt_items), ops(rt_items)
+    left[3] = left[3][:1]      # single-level items: every step compares level 0
+    right[5] = right[5][:1]
+    right[7] = list(left[3])
+    lcat = np.array([rng.choice([1, 2, 3, 4, 6]) for _ in left], dtype=np.uint64)
+    rcat = np.array([rng.choice([1, 2, 3, 5, 0]) for _ in right], dtype=np.uint64)
+    cps = lambda items: [[[ord(c) for c in s] for s in it] for it in items]
+    every = native.levels(True, cps(left), cps(right), 0.0, None, None, 0, cap=n_left * n_right)
+    assert len(every) == n_left * n_right
+    for mode, partition in ((_lib.CAT_NONE, True), (_lib.CAT_INTERSECT, True), (_lib.CAT_INTERSECT_OR_BOTH_EMPTY, False)):
+        li, ls, ri, rs = tables.encode_level_strings(left, right, dev, lcat, rcat, mode, partition=partition)
+        assert ls.stride == rs.stride == stride
+        if mode == _lib.CAT_NONE:
+            keep = lambda i, j: True
+        elif mode == _lib.CAT_INTERSECT:
+            keep = lambda i, j: bool(int(lcat[i]) & int(rcat[j]))
+        else:
+            keep = lambda i, j: bool(int(lcat[i]) & int(rcat[j])) or (not lcat[i] and not rcat[j])
+        for thr in (0.0, 0.2, 0.45, 0.7, 0.9):
+            want = [(s, i, j) for (s, i, j) in every if s >= thr and keep(i, j)]
+            got = grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, capacity=1 << 17)
+            _same_hits(got, want)
+            assert thr > 0.8 or len(want) > 0
+            if thr in (0.2, 0.7):
+                _same_hits(grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, capacity=1 << 17, park=True), want)
+                _same_hits(grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, capacity=1 << 17, prune=False), want)
