@@ -115,20 +115,19 @@ __global__ __launch_bounds__(tile_max_waves(K) * kWave) NSM_TILE_OCC void indel_
   uint8_t* lstr = reinterpret_cast<uint8_t*>(srow + kBatch * 2);
 
   // ---- which (right tile, left slice) this block works on.  Blocks are dealt to the 8 XCDs round-robin (block b
-  // runs on XCD b % 8) and every XCD has its own 4 MB L2: XCD x takes the x-th eighth of the tiles and walks it
-  // slice-major, so the blocks resident on one XCD at the same time read the SAME left slice (and, with a category
-  // partition, neighbouring tiles = the same category's rows) out of that XCD's L2.
+  // runs on XCD b % 8) and every XCD has its own 4 MB L2: each XCD walks its tiles slice-major, so the blocks resident
+  // on one XCD at the same time read the SAME left slice out of that XCD's L2.  XCD x takes the tiles x, x + 8, x + 16, ...:
+  // the tables are sorted by depth and length, so a contiguous eighth of the tiles would give XCD 0 the deepest items
+  // with the longest strings and XCD 7 the cheapest ones (measured: the chip 62 % occupied on average).
   int tile, yslice;
   {
     const int b = blockIdx.x;
     const int xcd = b & 7, k = b >> 3;
-    const int per = (p.n_tiles + 7) >> 3;           // tiles per XCD
-    const int t0 = xcd * per;
-    const int mine = max(0, min(per, p.n_tiles - t0));
-    // the linear grid has 8 * per * y_slices blocks (rounded up): block k of this XCD = (slice k / mine, tile k % mine)
-    if (mine == 0 || k >= mine * p.y_slices) return;  // (whole block: before any barrier)
+    const int mine = (p.n_tiles - xcd + 7) >> 3;    // tiles of this XCD
+    // the linear grid has 8 * ceil(n_tiles / 8) * y_slices blocks: block k of this XCD = (slice k / mine, its tile k % mine)
+    if (mine <= 0 || k >= mine * p.y_slices) return;  // (whole block: before any barrier)
     yslice = k / mine;
-    tile = t0 + (k - yslice * mine);
+    tile = xcd + 8 * (k - yslice * mine);
   }
   const int j = tile * kWave + lane;
   const bool valid = j < p.n_right;
