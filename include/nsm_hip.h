@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define NSM_ABI_VERSION 2
+#define NSM_ABI_VERSION 3
 
 #define NSM_E_BADARG 10001   /* inconsistent sizes / unsupported width */
 #define NSM_E_UNSUPPORTED 10002
@@ -223,6 +223,53 @@ int nsm_build_str_table(const uint8_t* codes_in, const int32_t* len_in, const in
  * with NSM_BUILD_PARTITION grouped by category (as nsm_build_set_table). */
 int nsm_build_level_items(const int32_t* first_in, const int32_t* nlev_in, const uint64_t* cat_in, const int32_t* orig_in,
                           int32_t n, int32_t category_mode, uint32_t flags, nsm_level_items* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Operands beyond the register-resident kernels (ABI 3): token sets of more than 64 ids, strings of more than 512 code
+ * units, alphabets of more than 255 symbols.  The reference has no size limits (compare/score_functions.py:10-13 builds
+ * Python sets of any size, :27 hands strings of any length to rapidfuzz).  Plain CSR operands in the CALLER's item order,
+ * no derived columns, no pruning: every pair that passes the category predicate is scored in full.  Meant for the FEW
+ * items that need it -- a host routes (wide items x all) and (all x wide items) through here and the rest through the
+ * grids above (napkon_string_matching_amd/wide.py does).  Caps: 4096 code units per string, 1023 symbols, 65535 ids
+ * per item, 64 levels; beyond them NSM_E_UNSUPPORTED.
+ */
+typedef struct nsm_any_strings {
+  const uint16_t* codes;   /* device: code units of all rows, concatenated */
+  const int64_t* offset;   /* device int64 [n_rows + 1]: row r = codes[offset[r] .. offset[r + 1]) */
+  int32_t n_rows;
+  int32_t alphabet;        /* code units are < alphabet (<= 1023), the same on both sides of a grid */
+  int32_t max_len;         /* longest row (<= 4096) */
+} nsm_any_strings;
+
+typedef struct nsm_any_items {   /* items whose levels are rows first .. first + nlev - 1 of an nsm_any_strings */
+  const int32_t* first;
+  const int32_t* nlev;
+  const int32_t* orig;     /* caller's item id reported in hits */
+  const uint64_t* cat;     /* category masks, or NULL with NSM_CAT_NONE */
+  int32_t n;
+} nsm_any_items;
+
+typedef struct nsm_any_sets {
+  const int32_t* ids;      /* device: every item's distinct ids SORTED BY ID, concatenated */
+  const uint8_t* lv;       /* device, parallel to ids: the first level of the item that contains the id (RAW: 0) */
+  const int64_t* offset;   /* device int64 [n + 1] */
+  const int32_t* nlev;     /* device int32 [n] (RAW: 1) */
+  const int32_t* plen;     /* device int32 [n][max_levels]: number of ids in level l (entries past the last level unused) */
+  const int32_t* orig;
+  const uint64_t* cat;
+  int32_t n;
+  int32_t max_levels;      /* row stride of plen, the same on both sides */
+  int32_t max_ids;         /* most ids in one item (<= 65535) */
+} nsm_any_sets;
+
+#define NSM_FLAG_RAW_SCORE 32u /* nsm_*_any_grid: score = score_func(level 0, level 0) (the RAW plugin call) instead of
+                                  compare_terms over the levels */
+
+int nsm_indel_any_grid(const nsm_any_items* left, const nsm_any_strings* left_strings, const nsm_any_items* right,
+                       const nsm_any_strings* right_strings, double threshold, int32_t category_mode, uint32_t flags,
+                       nsm_hit* hits, uint64_t capacity, unsigned long long* hit_count, void* stream);
+int nsm_jaccard_any_grid(const nsm_any_sets* left, const nsm_any_sets* right, double threshold, int32_t category_mode,
+                         uint32_t flags, nsm_hit* hits, uint64_t capacity, unsigned long long* hit_count, void* stream);
 
 /* In-place canonical ordering of the first min(*hit_count, capacity) hits:
  * score descending, then i, then j ascending.  `scratch` is a device buffer of the same capacity. */

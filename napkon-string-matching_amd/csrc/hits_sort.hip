@@ -5,11 +5,9 @@
 //
 // The number of hits lives in device memory (the grids append with an atomic counter), so the
 // launch geometry comes from `capacity` and every kernel reads the count itself:
-//   * up to 2048 live records (the common case): ONE workgroup sorts 128-bit integer keys
-//     (~score bits, i, j) with a bitonic network in LDS and writes the records back in place;
-//   * up to 8192 live records: rank sort -- each record counts its predecessors in one pass over
-//     LDS-staged tiles and is scattered to scratch[rank]; no inter-block dependency (O(n^2): 52 k
-//     records took 7 ms, hence the limit);
+//   * up to 8192 live records (the common case): ONE workgroup sorts 128-bit integer keys
+//     (~score bits, i, j) with a bitonic network in LDS (16 bytes per record, 128 KB at most) and
+//     writes the records back in place -- a single launch;
 //   * more: bitonic network, "flip" form (all comparators point the same way), which needs no
 //     padding to a power of two.  Every comparator pass whose partner distance is below 2048 stays
 //     inside an aligned 2048-record tile, so those passes run fused in LDS (one launch sorts all
@@ -31,7 +29,7 @@ __device__ __forceinline__ unsigned long long live_count(const unsigned long lon
   return c < capacity ? c : capacity;
 }
 
-constexpr int kSmallSortMax = 2048;
+constexpr int kSmallSortMax = 8192;  // one workgroup, 128-bit keys in LDS: 128 KB of the CU's 160 KB at the maximum
 constexpr unsigned long long kRankSortMax = 8192;
 constexpr int kSmallSortThreads = 1024;
 
@@ -43,14 +41,15 @@ __device__ __forceinline__ unsigned long long score_key(double score) {
 }
 
 __global__ __launch_bounds__(kSmallSortThreads) void small_sort_kernel(
-    nsm_hit* __restrict__ hits, unsigned long long capacity, const unsigned long long* __restrict__ count) {
-  __shared__ unsigned long long key_hi[kSmallSortMax];
-  __shared__ unsigned long long key_lo[kSmallSortMax];
+    nsm_hit* __restrict__ hits, unsigned long long capacity, const unsigned long long* __restrict__ count, int lds_records) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];  // [p] high words | [p] low words, p <= lds_records
   const unsigned long long n64 = live_count(count, capacity);
-  if (n64 < 2 || n64 > kSmallSortMax) return;
+  if (n64 < 2 || n64 > static_cast<unsigned long long>(lds_records)) return;
   const int n = static_cast<int>(n64);
   int p = 2;
   while (p < n) p <<= 1;
+  unsigned long long* key_hi = s_keys;
+  unsigned long long* key_lo = s_keys + p;
   for (int t = threadIdx.x; t < p; t += kSmallSortThreads) {
     if (t < n) {
       const nsm_hit h = hits[t];
@@ -88,43 +87,6 @@ __global__ __launch_bounds__(kSmallSortThreads) void small_sort_kernel(
     h.j = static_cast<int32_t>(static_cast<uint32_t>(key_lo[t]) ^ 0x80000000u);
     hits[t] = h;
   }
-}
-
-__global__ __launch_bounds__(kBlock) void rank_sort_kernel(const nsm_hit* __restrict__ hits,
-                                                           nsm_hit* __restrict__ out,
-                                                           unsigned long long capacity,
-                                                           const unsigned long long* __restrict__ count) {
-  __shared__ nsm_hit tile[kBlock];
-  const unsigned long long n = live_count(count, capacity);
-  if (n <= kSmallSortMax || n > kRankSortMax) return;  // small_sort_kernel's / the bitonic passes' job
-  const unsigned long long base = static_cast<unsigned long long>(blockIdx.x) * kBlock;
-  if (base >= n) return;  // whole block
-  const unsigned long long idx = base + threadIdx.x;
-  const bool live = idx < n;
-  nsm_hit mine;
-  if (live) mine = hits[idx];
-  unsigned long long rank = 0;
-  for (unsigned long long t0 = 0; t0 < n; t0 += kBlock) {
-    __syncthreads();
-    if (t0 + threadIdx.x < n) tile[threadIdx.x] = hits[t0 + threadIdx.x];
-    __syncthreads();
-    const int m = static_cast<int>(n - t0 < kBlock ? n - t0 : kBlock);
-    if (live) {
-      for (int q = 0; q < m; ++q) rank += hit_before(tile[q], mine) ? 1u : 0u;
-    }
-  }
-  if (live) out[rank] = mine;
-}
-
-__global__ __launch_bounds__(kBlock) void copy_hits_kernel(const nsm_hit* __restrict__ src,
-                                                           nsm_hit* __restrict__ dst,
-                                                           unsigned long long capacity,
-                                                           const unsigned long long* __restrict__ count) {
-  const unsigned long long n = live_count(count, capacity);
-  if (n <= kSmallSortMax || n > kRankSortMax) return;  // sorted in place by the other kernels
-  for (unsigned long long idx = static_cast<unsigned long long>(blockIdx.x) * kBlock + threadIdx.x; idx < n;
-       idx += static_cast<unsigned long long>(gridDim.x) * kBlock)
-    dst[idx] = src[idx];
 }
 
 // One comparator pass of the flip-form bitonic network: k = merge size, j = partner distance
@@ -214,19 +176,26 @@ extern "C" int nsm_sort_hits(nsm_hit* hits, nsm_hit* scratch, uint64_t capacity,
   }
   if (capacity == 0) return 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(small_sort_kernel, dim3(1), dim3(kSmallSortThreads), 0, s, hits, capacity, hit_count);
+  // up to 8192 live records: ONE launch of one workgroup (bitonic network on 128-bit keys in LDS).  Round 2 sorted
+  // 2049..8192 records with a rank-sort launch plus a copy launch; both were launched for every capacity above 2048
+  // (the count lives on the device) and two empty launches cost the headline step more than they ever saved.
+  const int lds_records = static_cast<int>(capacity < kSmallSortMax ? (capacity < 2 ? 2 : capacity) : kSmallSortMax);
+  int p2 = 2;
+  while (p2 < lds_records) p2 <<= 1;
+  static bool attr_set = false;
+  if (!attr_set) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&small_sort_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, kSmallSortMax * 16);
+    if (e != hipSuccess) return hip_status(e, "hipFuncSetAttribute(small_sort_kernel)");
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(small_sort_kernel, dim3(1), dim3(kSmallSortThreads), static_cast<size_t>(p2) * 16, s, hits, capacity,
+                     hit_count, p2);
   if (capacity <= kSmallSortMax) return hip_status(hipGetLastError(), "nsm_sort_hits (small)");
   if (!scratch) {
     set_error("nsm_sort_hits: scratch buffer required");
     return NSM_E_BADARG;
   }
-  {
-    const unsigned long long live_max = capacity < kRankSortMax ? capacity : kRankSortMax;
-    const unsigned blocks = static_cast<unsigned>((live_max + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(rank_sort_kernel, dim3(blocks), dim3(kBlock), 0, s, hits, scratch, capacity, hit_count);
-    hipLaunchKernelGGL(copy_hits_kernel, dim3(blocks), dim3(kBlock), 0, s, scratch, hits, capacity, hit_count);
-  }
-  if (capacity <= kRankSortMax) return hip_status(hipGetLastError(), "nsm_sort_hits (rank sort)");
   unsigned long long blocks64 = (capacity + kBlock - 1) / kBlock;
   const unsigned blocks = static_cast<unsigned>(blocks64 < 8192 ? blocks64 : 8192);
   unsigned long long tiles64 = (capacity + kTile - 1) / kTile;

@@ -376,7 +376,12 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
                      left->first, left->nlev, left->orig, left->cat, left->seg_start, left_strings->codes,     \
                      left_strings->len, right->first, right->nlev, right->orig, right->cat, right->seg,         \
                      right_strings->codes, right_strings->len, hits, hit_count, p)
-  if (!(flags & NSM_FLAG_WAVE_WIDE) && K > 1 && !(flags & NSM_FLAG_PARK)) {
+  // (One-word strings stay on the park kernel: its scan is built around texts held in registers as packed LDS
+  // addresses and 16-dword folded histograms; the shared-tile kernel instantiated for K = 1 -- with the same packed
+  // two-row pass -- ran configs[4]'s fuzzy grids in 660 ms against 418 ms: per left row its H phase and double-precision
+  // bookkeeping cost more than the 27-code-unit LCS they guard.)
+  const bool tile_ok = K > 1;
+  if (!(flags & NSM_FLAG_WAVE_WIDE) && tile_ok && !(flags & NSM_FLAG_PARK)) {
     // multi-word strings: shared-tile kernel (indel_levels_tile.hpp) -- the waves of a block share one right tile
     // whose level strings stay resident in LDS, and divide the left rows
     TileParams q;
@@ -435,6 +440,12 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
     long long slices = (256ll * NSM_TILE_ROUNDS + n_tiles - 1) / n_tiles;
     const long long max_slices = rows_cat / (static_cast<long long>(tw) * kTileBatch * 4) + 1;
     if (slices > max_slices) slices = max_slices;
+    // ... and left slices that stay in an XCD's 4 MB L2 while its blocks (neighbouring tiles) walk them: <= 4096 rows
+    // (heads, histograms and two level strings per row: ~0.2 KB + 2 x 64 K bytes)
+#ifndef NSM_TILE_SLICE_ROWS
+#define NSM_TILE_SLICE_ROWS 4096
+#endif
+    if (slices < rows_cat / NSM_TILE_SLICE_ROWS) slices = rows_cat / NSM_TILE_SLICE_ROWS;
     if (slices < 1) slices = 1;
     if (slices > 4096) slices = 4096;
     q.y_slices = static_cast<int>(slices);

@@ -6,10 +6,11 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("NSM_HIP_LIBRARY", _HERE.parent / "csrc" / "libnsm_hip.so"))
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 FLAG_PRUNE = 1
 FLAG_WAVE_WIDE = 2  # nsm_indel_levels_grid without the block-cooperative parking (A/B runs, tests)
 FLAG_INDEX, FLAG_NO_INDEX = 4, 8  # nsm_jaccard_raw_grid: force / forbid the inverted-index kernel
+FLAG_RAW_SCORE = 32  # nsm_*_any_grid: the RAW plugin call instead of compare_terms
 FLAG_PARK = 16  # nsm_indel_levels_grid, strings > 64 code units: the round-2 park kernel instead of the shared-tile kernel
 BUILD_PARTITION, BUILD_VALIDATE, BUILD_SORT = 1, 2, 4
 CAT_NONE, CAT_INTERSECT, CAT_INTERSECT_OR_BOTH_EMPTY = 0, 1, 2
@@ -55,6 +56,22 @@ class NsmStrTable(ctypes.Structure):
     ]
 
 
+class NsmAnyStrings(ctypes.Structure):
+    _fields_ = [("codes", ctypes.c_void_p), ("offset", ctypes.c_void_p), ("n_rows", ctypes.c_int32),
+                ("alphabet", ctypes.c_int32), ("max_len", ctypes.c_int32)]
+
+
+class NsmAnyItems(ctypes.Structure):
+    _fields_ = [("first", ctypes.c_void_p), ("nlev", ctypes.c_void_p), ("orig", ctypes.c_void_p), ("cat", ctypes.c_void_p),
+                ("n", ctypes.c_int32)]
+
+
+class NsmAnySets(ctypes.Structure):
+    _fields_ = [("ids", ctypes.c_void_p), ("lv", ctypes.c_void_p), ("offset", ctypes.c_void_p), ("nlev", ctypes.c_void_p),
+                ("plen", ctypes.c_void_p), ("orig", ctypes.c_void_p), ("cat", ctypes.c_void_p), ("n", ctypes.c_int32),
+                ("max_levels", ctypes.c_int32), ("max_ids", ctypes.c_int32)]
+
+
 class NsmLevelItems(ctypes.Structure):
     _fields_ = [
         ("first", ctypes.c_void_p),
@@ -78,6 +95,8 @@ EXPORTS = (
     "nsm_build_set_table",
     "nsm_build_str_table",
     "nsm_build_level_items",
+    "nsm_indel_any_grid",
+    "nsm_jaccard_any_grid",
 )
 
 _lib = None
@@ -111,6 +130,10 @@ def load() -> ctypes.CDLL:
     lib.nsm_indel_levels_grid.argtypes = [
         P(NsmLevelItems), P(NsmStrTable), P(NsmLevelItems), P(NsmStrTable),
         ctypes.c_double, ctypes.c_int32, ctypes.c_uint32] + grid_tail
+    lib.nsm_indel_any_grid.argtypes = [
+        P(NsmAnyItems), P(NsmAnyStrings), P(NsmAnyItems), P(NsmAnyStrings), ctypes.c_double, ctypes.c_int32,
+        ctypes.c_uint32] + grid_tail
+    lib.nsm_jaccard_any_grid.argtypes = [P(NsmAnySets), P(NsmAnySets), ctypes.c_double, ctypes.c_int32, ctypes.c_uint32] + grid_tail
     lib.nsm_sort_hits.argtypes = [ctypes.c_void_p, ctypes.c_void_p, c_u64, ctypes.c_void_p, ctypes.c_void_p]
     vp, i32, u32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32
     lib.nsm_build_set_table.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, i32, u32, P(NsmSetTable), vp]

@@ -81,16 +81,29 @@ class _IntersectionVsUnion:
     @staticmethod
     def raw_grid(left_items: Sequence[Operand], right_items: Sequence[Operand], threshold: float, device=None,
                  prune: bool = True) -> grid.Hits:
+        from .. import wide
+
         dev = device or _device()
-        vocab = tables.Vocabulary()
-        l_rows = [set_operand(v) for v in left_items]
-        r_rows = [set_operand(v) for v in right_items]
-        width = tables.pick_width(
-            max((len(set(r)) for r in l_rows), default=1), max((len(set(r)) for r in r_rows), default=1)
-        )
-        lt = tables.SetTable.from_rows(l_rows, "left", dev, vocab, width=width)
-        rt = tables.SetTable.from_rows(r_rows, "right", dev, vocab, width=width)
-        return grid.jaccard_raw_grid(lt, rt, threshold, prune=prune)
+        l_rows = [list(set_operand(v)) for v in left_items]
+        r_rows = [list(set_operand(v)) for v in right_items]
+
+        def fast(li, ri):
+            vocab = tables.Vocabulary()
+            ls, rs = [l_rows[k] for k in li], [r_rows[k] for k in ri]
+            width = tables.pick_width(max((len(set(r)) for r in ls), default=1), max((len(set(r)) for r in rs), default=1))
+            lt = tables.SetTable.from_rows(ls, "left", dev, vocab, width=width)
+            rt = tables.SetTable.from_rows(rs, "right", dev, vocab, width=width)
+            return grid.jaccard_raw_grid(lt, rt, threshold, prune=prune)
+
+        split = wide.wide_set_items([[r] for r in l_rows], [[r] for r in r_rows])
+        if split is None:
+            return fast(range(len(l_rows)), range(len(r_rows)))
+        # items of more than 64 distinct tokens (the reference's set(...) has no size limit, score_functions.py:10-13)
+        if any(not r for r in l_rows) and any(not r for r in r_rows):
+            raise ZeroDivisionError("division by zero")  # (:13, checked on the whole grid before it is split)
+        general = lambda li, ri: wide.jaccard_any_grid([[l_rows[k]] for k in li], [[r_rows[k]] for k in ri], threshold,
+                                                       raw=True, device=dev)
+        return wide.split_grid(split[0], split[1], fast, general)
 
 
 class _FuzzyMatch:
@@ -104,11 +117,22 @@ class _FuzzyMatch:
     @staticmethod
     def raw_grid(left_items: Sequence[Operand], right_items: Sequence[Operand], threshold: float, device=None,
                  prune: bool = True) -> grid.Hits:
+        from .. import wide
+
         dev = device or _device()
-        lt, rt = tables.encode_strings(
-            [fuzzy_operand(v) for v in left_items], [fuzzy_operand(v) for v in right_items], dev
-        )
-        return grid.indel_raw_grid(lt, rt, threshold, prune=prune)
+        l_ops, r_ops = [fuzzy_operand(v) for v in left_items], [fuzzy_operand(v) for v in right_items]
+
+        def fast(li, ri):
+            lt, rt = tables.encode_strings([l_ops[k] for k in li], [r_ops[k] for k in ri], dev)
+            return grid.indel_raw_grid(lt, rt, threshold, prune=prune)
+
+        split = wide.wide_string_items([[s] for s in l_ops], [[s] for s in r_ops])
+        if split is None:
+            return fast(range(len(l_ops)), range(len(r_ops)))
+        # strings of more than 512 code units / more than 255 distinct code units (rapidfuzz has no such limit, :27)
+        general = lambda li, ri: wide.indel_any_grid([[l_ops[k]] for k in li], [[r_ops[k]] for k in ri], threshold, raw=True,
+                                                     device=dev)
+        return wide.split_grid(split[0], split[1], fast, general)
 
 
 intersection_vs_union = _IntersectionVsUnion()

@@ -630,6 +630,12 @@ def _raise_first_pair_error(is_sets, levels_l, levels_r, nlev_l, nlev_r, n_r, su
         raise ZeroDivisionError("division by zero")
 
 
+def _may_be_wide_sets(*sides) -> bool:
+    """Cheap pre-check of the 64-token limit: the largest level's token count WITH repeats (strings: words)."""
+    size = lambda lv: len(lv) if isinstance(lv, list) else len(lv.split())
+    return any(size(it[-1]) > 64 for items in sides for it in items if len(it))
+
+
 def _levels_grid(plugin, levels_l, levels_r, threshold, cat_l, cat_r, cat_mode=_lib.CAT_NONE) -> grid.Hits:
     """Encode both sides' levels for ``plugin`` and run the levels grid on the current device."""
     import torch
@@ -637,8 +643,22 @@ def _levels_grid(plugin, levels_l, levels_r, threshold, cat_l, cat_r, cat_mode=_
     if not torch.cuda.is_available():
         raise _lib.NsmLibraryError("the match loop runs on an MI355X (HIP device); there is no CPU fallback")
     dev = torch.device("cuda", torch.cuda.current_device())
+    from .. import wide
+
+    sub = lambda seq, idx: [seq[k] for k in idx]
+    cut = lambda cat, idx: None if cat is None else np.asarray(cat)[np.asarray(idx, dtype=np.int64)]
     if plugin.kind == "sets":
         as_set_levels = lambda it: [lv if isinstance(lv, list) else lv.split() for lv in it]
+        split = wide.wide_set_items([as_set_levels(it) for it in levels_l], [as_set_levels(it) for it in levels_r]) \
+            if _may_be_wide_sets(levels_l, levels_r) else None
+        if split is not None:
+            # items of more than 64 distinct tokens leave the fast path (wide.py); the rest is scored as always
+            fast = lambda li, ri: _levels_grid(plugin, sub(levels_l, li), sub(levels_r, ri), threshold, cut(cat_l, li),
+                                               cut(cat_r, ri), cat_mode)
+            general = lambda li, ri: wide.jaccard_any_grid(
+                [as_set_levels(levels_l[k]) for k in li], [as_set_levels(levels_r[k]) for k in ri], threshold, cut(cat_l, li),
+                cut(cat_r, ri), cat_mode, device=dev)
+            return wide.split_grid(split[0], split[1], fast, general)
         part = tables.partition_allowed(cat_mode, cat_l, cat_r)
         memo = ComparableData._item_memo
         if memo is not None:
@@ -669,5 +689,16 @@ def _levels_grid(plugin, levels_l, levels_r, threshold, cat_l, cat_r, cat_mode=_
         return grid.jaccard_levels_grid(lt, rt, threshold, category_mode=cat_mode)
     prep = lambda items: ComparableData._memoised(
         "fuzzy", items, lambda it: [score_functions.fuzzy_operand(lv) for lv in it])
-    li, ls, ri, rs = tables.encode_level_strings(prep(levels_l), prep(levels_r), dev, cat_l, cat_r, cat_mode)
+    ops_l, ops_r = prep(levels_l), prep(levels_r)
+    split = wide.wide_string_items(ops_l, ops_r)
+    if split is not None:
+        # level strings of more than 512 code units / a grid of more than 255 distinct code units (wide.py)
+        def fast(li, ri):
+            a, b, c, d = tables.encode_level_strings(sub(ops_l, li), sub(ops_r, ri), dev, cut(cat_l, li), cut(cat_r, ri), cat_mode)
+            return grid.indel_levels_grid(a, b, c, d, threshold, category_mode=cat_mode)
+
+        general = lambda li, ri: wide.indel_any_grid(sub(ops_l, li), sub(ops_r, ri), threshold, cut(cat_l, li), cut(cat_r, ri),
+                                                     cat_mode, device=dev)
+        return wide.split_grid(split[0], split[1], fast, general)
+    li, ls, ri, rs = tables.encode_level_strings(ops_l, ops_r, dev, cat_l, cat_r, cat_mode)
     return grid.indel_levels_grid(li, ls, ri, rs, threshold, category_mode=cat_mode)
