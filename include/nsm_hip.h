@@ -145,9 +145,9 @@ typedef struct nsm_level_items {
 #define NSM_CAT_INTERSECT_OR_BOTH_EMPTY 2 /* list x list */
 
 #define NSM_FLAG_PRUNE 1u /* exact signature / length bound before the full comparison */
-#define NSM_FLAG_INDEX 4u    /* nsm_jaccard_raw_grid: candidate generation by inverted index (chosen by itself at low
-                                thresholds, where the signature prune stops paying; this forces it) */
-#define NSM_FLAG_NO_INDEX 8u /* nsm_jaccard_raw_grid: never use the inverted index (A/B runs, tests) */
+#define NSM_FLAG_INDEX 4u    /* nsm_jaccard_raw_grid, nsm_jaccard_levels_grid: candidate generation by inverted index (chosen by
+                                itself at low thresholds, where the signature filter stops paying; this forces it) */
+#define NSM_FLAG_NO_INDEX 8u /* the same grids: never use the inverted index (A/B runs, tests) */
 #define NSM_FLAG_PARK 16u /* nsm_indel_levels_grid, strings beyond 64 code units: the round-2 kernel (one right tile per
                              wavefront, block-shared park) instead of the shared-tile kernel; same hits, A/B runs and tests */
 #define NSM_FLAG_WAVE_WIDE 2u /* nsm_indel_levels_grid: score every step wave-wide (no block-cooperative

@@ -13,7 +13,24 @@ NSM_DECL(16)
 NSM_DECL(32)
 NSM_DECL(64)
 #undef NSM_DECL
+template <int W>
+int launch_levels_index(const nsm_set_table* l, const nsm_set_table* r, double threshold, int32_t category_mode, nsm_hit* hits,
+                        uint64_t capacity, unsigned long long* hit_count, hipStream_t stream);
+extern template int launch_levels_index<16>(const nsm_set_table*, const nsm_set_table*, double, int32_t, nsm_hit*, uint64_t,
+                                            unsigned long long*, hipStream_t);
+extern template int launch_levels_index<32>(const nsm_set_table*, const nsm_set_table*, double, int32_t, nsm_hit*, uint64_t,
+                                            unsigned long long*, hipStream_t);
 }  // namespace nsm
+
+// Below these thresholds one or two common ids already pass the signature filter of jaccard_levels_kernel for most pairs,
+// and candidates come from the per-tile inverted index instead (jaccard_levels_index.hip); NSM_FLAG_INDEX / NSM_FLAG_NO_INDEX
+// force / forbid it.  (Sweep: DESIGN.md section 4.2.)
+#ifndef NSM_LEV_INDEX_BELOW_16
+#define NSM_LEV_INDEX_BELOW_16 0.45
+#endif
+#ifndef NSM_LEV_INDEX_BELOW_32
+#define NSM_LEV_INDEX_BELOW_32 0.65
+#endif
 
 extern "C" int nsm_jaccard_levels_grid(const nsm_set_table* left, const nsm_set_table* right, double threshold,
                                        int32_t category_mode, uint32_t flags, nsm_hit* hits, uint64_t capacity,
@@ -52,6 +69,14 @@ extern "C" int nsm_jaccard_levels_grid(const nsm_set_table* left, const nsm_set_
     return NSM_E_BADARG;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (threshold > 0.0 && !(flags & NSM_FLAG_NO_INDEX) && (left->width == 16 || left->width == 32)) {
+    // (a pair without a common id scores exactly 0: with a positive threshold only pairs that share an id can hit)
+    const double below = left->width == 16 ? NSM_LEV_INDEX_BELOW_16 : NSM_LEV_INDEX_BELOW_32;
+    if ((flags & NSM_FLAG_INDEX) || threshold < below) {
+      if (left->width == 16) return launch_levels_index<16>(left, right, threshold, category_mode, hits, capacity, hit_count, s);
+      return launch_levels_index<32>(left, right, threshold, category_mode, hits, capacity, hit_count, s);
+    }
+  }
   switch (left->width) {
     case 16: return launch_levels<16>(left, right, threshold, category_mode, flags, hits, capacity, hit_count, s);
     case 32: return launch_levels<32>(left, right, threshold, category_mode, flags, hits, capacity, hit_count, s);

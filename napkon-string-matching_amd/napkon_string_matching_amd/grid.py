@@ -141,14 +141,15 @@ def indel_raw_grid(
 # ------------------------------------------------------------------------------- levels grids
 def jaccard_levels_grid(
     left: SetTable, right: SetTable, threshold: float, category_mode: int = _lib.CAT_NONE, prune: bool = True,
-    capacity: Optional[int] = None,
+    capacity: Optional[int] = None, index: Optional[bool] = None,
 ) -> Hits:
-    """``compare_terms`` with ``intersection_vs_union`` over suffix-nested levels."""
+    """``compare_terms`` with ``intersection_vs_union`` over suffix-nested levels.
+    ``index``: None = the library decides (inverted-index candidates at low thresholds), True / False = force."""
     if left.nlev is None or right.nlev is None:
         raise ValueError("levels grid needs tables built with SetTable.from_levels")
     lib = _lib.load()
     ls, rs = left.struct(), right.struct()
-    flags = _lib.FLAG_PRUNE if prune else 0
+    flags = (_lib.FLAG_PRUNE if prune else 0) | (0 if index is None else (_lib.FLAG_INDEX if index else _lib.FLAG_NO_INDEX))
     if (left.seg is None) != (right.seg is None) or left.category_mode != right.category_mode:
         raise ValueError("both sides must be encoded alike: same category_mode and partition (tables.partition_allowed)")
     if left.category_mode is not None:  # the encoder may have rewritten the predicate (partition)

@@ -328,6 +328,9 @@ def test_jaccard_levels_random(dev, vocab, max_levels, max_new):
             assert thr > 0.9 or len(want) > 0
             got = grid.jaccard_levels_grid(lt, rt, thr, category_mode=mode, capacity=1 << 12)
             _same_hits(got, want)
+            if thr > 0.0 and width <= 32:  # candidates from the per-tile inverted index / from the signature filter
+                _same_hits(grid.jaccard_levels_grid(lt, rt, thr, category_mode=mode, capacity=1 << 12, index=True), want)
+                _same_hits(grid.jaccard_levels_grid(lt, rt, thr, category_mode=mode, capacity=1 << 12, index=False), want)
 
 
 def test_jaccard_levels_identical_items(dev):
@@ -512,3 +515,40 @@ def test_indel_levels_term_like(dev, entries, words, n_left, n_right, stride):
             if thr in (0.2, 0.7):
                 _same_hits(grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, capacity=1 << 17, park=True), want)
                 _same_hits(grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, capacity=1 << 17, prune=False), want)
+
+
+@pytest.mark.parametrize("vocab", [20_000, 1 << 17])
+def test_jaccard_levels_c5_shaped_low_threshold(dev, vocab):
+    """configs[4]-shaped cohorts (4 levels, ~8 ids, 1-2 of 32 categories, category partition) at the API's default
+    threshold 0.1 (types/comparable_data.py:75), 25k x 25k: the inverted-index kernel (chosen by the library below
+    0.45), the signature-filter kernel and the C oracle agree bit for bit."""
+    from napkon_string_matching_amd import _lib, grid, synthetic, tables
+    from oracle import native
+
+    n = 25_000
+    hap = synthetic.c5_cohort(n, 41, vocab=vocab)
+    pop = synthetic.c5_cohort(n, 42, vocab=vocab, plant_from=hap)
+    mode = _lib.CAT_INTERSECT_OR_BOTH_EMPTY
+    hap["cat"][:40] = 0
+    pop["cat"][:60] = 0
+    lt = tables.SetTable.from_nested_arrays(hap["ids"], hap["plen"], hap["nlev"], "left", dev, categories=hap["cat"], width=16,
+                                            category_mode=mode)
+    rt = tables.SetTable.from_nested_arrays(pop["ids"], pop["plen"], pop["nlev"], "right", dev, categories=pop["cat"], width=16,
+                                            category_mode=mode)
+    assert lt.seg is not None
+    auto = grid.jaccard_levels_grid(lt, rt, 0.1, category_mode=mode, capacity=1 << 18)
+    matrix = grid.jaccard_levels_grid(lt, rt, 0.1, category_mode=mode, capacity=1 << 18, index=False)
+    forced = grid.jaccard_levels_grid(lt, rt, 0.1, category_mode=mode, capacity=1 << 18, index=True)
+    assert auto.as_tuples() == matrix.as_tuples() == forced.as_tuples() and len(auto) > 200
+    ids = lambda c: [[[int(t[1:]) for t in level] for level in item] for item in synthetic.c5_level_token_lists(c)]
+    want = native.levels(False, ids(hap), ids(pop), 0.1, hap["cat"], pop["cat"], mode, cap=1 << 18)
+    _same_hits(auto, want)
+    # without a partition (per-lane predicate) and without categories
+    for m, part in ((mode, False), (_lib.CAT_NONE, False)):
+        lt2 = tables.SetTable.from_nested_arrays(hap["ids"][:6000], hap["plen"][:6000], hap["nlev"][:6000], "left", dev,
+                                                 categories=hap["cat"][:6000], width=16, category_mode=m, partition=part)
+        rt2 = tables.SetTable.from_nested_arrays(pop["ids"][:7000], pop["plen"][:7000], pop["nlev"][:7000], "right", dev,
+                                                 categories=pop["cat"][:7000], width=16, category_mode=m, partition=part)
+        a = grid.jaccard_levels_grid(lt2, rt2, 0.1, category_mode=m, capacity=1 << 18, index=True)
+        b = grid.jaccard_levels_grid(lt2, rt2, 0.1, category_mode=m, capacity=1 << 18, index=False)
+        assert a.as_tuples() == b.as_tuples() and len(a) > 0

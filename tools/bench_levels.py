@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--check", type=int, default=0)
     ap.add_argument("--threshold", type=float, default=0.7)
     ap.add_argument("--vocab", type=int, default=20_000)
+    ap.add_argument("--jaccard-flags", type=int, default=1, help="flags of nsm_jaccard_levels_grid: 1 | 4 (force index) | 8 (no index)")
     ap.add_argument("--tokens-per-entry", type=int, default=2,
                     help="words per entry; 6 makes the level strings 40..170 code units (multi-word Indel kernels)")
     args = ap.parse_args()
@@ -72,7 +73,7 @@ def main():
     def run_jaccard(a, b):
         buf.count.zero_()
         _lib.check(lib.nsm_jaccard_levels_grid(set_tables[a, "left"].struct(), set_tables[b, "right"].struct(),
-                                               args.threshold, set_tables[a, "left"].category_mode, 1, buf.records.data_ptr(), buf.capacity,
+                                               args.threshold, set_tables[a, "left"].category_mode, args.jaccard_flags, buf.records.data_ptr(), buf.capacity,
                                                buf.count.data_ptr(), stream), "jaccard_levels")
         lib.nsm_sort_hits(buf.records.data_ptr(), buf.scratch.data_ptr(), buf.capacity, buf.count.data_ptr(), stream)
 
