@@ -497,12 +497,15 @@ def run_c5(args, comm, device, steps=None, warmup=None, cpu=True, sub=False):
     stream = torch.cuda.current_stream(device).cuda_stream
     turn = [0]
     counts = []
+    jaccard_flags = _lib.FLAG_PRUNE | (_lib.FLAG_INDEX if threshold > 0 else 0)
 
     def launch(g, b):
         kind, _keep, st, cat_mode = g
         if kind == "jaccard":
-            rc = lib.nsm_jaccard_levels_grid(st[0], st[1], float(threshold), cat_mode, 1, b.records.data_ptr(), b.capacity,
-                                             b.count.data_ptr(), stream)
+            # (the product's host path forces the inverted-index kernel when the vocabulary has >= 8192 tokens --
+            # types/comparable_data.py:_levels_grid; the synthetic cohorts draw from 20 000 words)
+            rc = lib.nsm_jaccard_levels_grid(st[0], st[1], float(threshold), cat_mode, jaccard_flags, b.records.data_ptr(),
+                                             b.capacity, b.count.data_ptr(), stream)
         else:
             rc = lib.nsm_indel_levels_grid(st[0], st[1], st[2], st[3], float(threshold), cat_mode, 1, b.records.data_ptr(),
                                            b.capacity, b.count.data_ptr(), stream)
