@@ -14,14 +14,14 @@ mkdir -p $out
 for part in $parts; do
   case $part in
   bench)
-    python3 bench.py > $out/c2_bench.json 2> $out/c2_bench.err; echo "c2 bench done"
-    for w in c2low c3 c4 term; do python3 bench.py --workload $w > $out/${w}_bench.json 2> $out/${w}_bench.err; echo "$w bench done"; done
-    python3 bench.py --workload c5 --steps 3 --warmup 1 > $out/c5_bench.json 2> $out/c5_bench.err; echo "c5 bench done"
+    # the default run carries every workload as a sub-record (c2 headline + c2low c3 c4 c5 term)
+    python3 bench.py > $out/all_bench.json 2> $out/all_bench.err; echo "default bench (all workloads) done"
     python3 tools/bench_levels.py --rows 100000 --steps 5 --check 300 > $out/levels_bench.json 2> $out/levels_bench.err; echo "levels bench done"
+    python3 tools/bench_levels.py --rows 100000 --steps 5 --threshold 0.1 > $out/levels01_bench.json 2> $out/levels01_bench.err; echo "levels bench at 0.1 done"
     python3 tools/bench_terms.py --rows 50000 --check 200 > $out/terms_bench.json 2> $out/terms_bench.err; echo "terms bench done"
     ;;
   trace)
-    for w in c2 c5 term; do
+    for w in c2 c3 c5 term; do
       steps=10; [ $w = c5 ] && steps=2
       rm -rf $out/prof_$w
       rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$w -- python3 bench.py --workload $w --steps $steps --warmup 2 --no-cpu-baseline > $out/prof_$w.log 2>&1
