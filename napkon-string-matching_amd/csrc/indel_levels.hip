@@ -396,7 +396,7 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
 #endif
     q.park_max = NSM_TILE_PARK_MAX;
     q.park_slots = kTileBatch * q.park_max;  // a row parks at most once, <= park_max pairs; drained after every batch
-    const size_t tbl_bytes = static_cast<size_t>(q.pm_stride) * tile_words(K) * 8;
+    const size_t tbl_bytes = (static_cast<size_t>(q.pm_stride) * tile_words(K) + kTileTableSkew) * 8;
     const size_t wave_bytes = (kTileTables * tbl_bytes + kTileBatch * 3 * kTileHead * 4 + 2 * kTileBatch * kWave * K +
                                kTileBatch * 2 * 4 + static_cast<size_t>(q.park_slots) * 12 + 15) & ~static_cast<size_t>(15);
     auto block_bytes = [&](int n_img) -> size_t {

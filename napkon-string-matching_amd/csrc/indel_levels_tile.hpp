@@ -104,11 +104,14 @@ __global__ __launch_bounds__(tile_max_waves(K) * kWave) NSM_TILE_OCC void indel_
   int* s_next = reinterpret_cast<int*>(wtab + 66);  // next batch of the block (16 bytes reserved)
   unsigned char* wbase0 = reinterpret_cast<unsigned char*>(wtab + 67);
   const int tbl_entries = p.pm_stride * kTileWords<K>;
-  const size_t wave_bytes = static_cast<size_t>(kTileTables) * tbl_entries * 8 + kBatch * 3 * kTileHead * 4 +
+  // distance between a wave's tables: tbl_entries u64 plus a skew, so that the SAME symbol of different tables (the dense
+  // pass reads one table per batch row) does not sit on the same LDS banks
+  const int tbl_stride = tbl_entries + kTileTableSkew;
+  const size_t wave_bytes = static_cast<size_t>(kTileTables) * tbl_stride * 8 + kBatch * 3 * kTileHead * 4 +
                             2 * kBatch * kRow + kBatch * 2 * 4 + static_cast<size_t>(p.park_slots) * 12;
   unsigned char* wbase = wbase0 + wave * ((wave_bytes + 15) & ~static_cast<size_t>(15));
   unsigned long long* pm = reinterpret_cast<unsigned long long*>(wbase);
-  double* pk_score = reinterpret_cast<double*>(pm + static_cast<size_t>(kTileTables) * tbl_entries);
+  double* pk_score = reinterpret_cast<double*>(pm + static_cast<size_t>(kTileTables) * tbl_stride);
   uint32_t* pk_meta = reinterpret_cast<uint32_t*>(pk_score + p.park_slots);
   uint32_t* head = pk_meta + p.park_slots;
   int32_t* srow = reinterpret_cast<int32_t*>(head + kBatch * 3 * kTileHead);
@@ -285,11 +288,11 @@ __global__ __launch_bounds__(tile_max_waves(K) * kWave) NSM_TILE_OCC void indel_
             left_level(q, s, lrow_q, la_q);
             const uint8_t* src = s == 2 ? lstr + (kBatch + q) * kRow
                                  : (s == 3 && staged3) ? lstr + q * kRow : lcodes + static_cast<size_t>(lrow_q) * kRow;
-            build_table(pm + static_cast<size_t>(q) * tbl_entries, src, la_q);
+            build_table(pm + static_cast<size_t>(q) * tbl_stride, src, la_q);
             la_max = max(la_max, la_q);
           }
         }
-        const unsigned long long* tbl = pm + static_cast<size_t>(fresh ? r : 0) * tbl_entries;
+        const unsigned long long* tbl = pm + static_cast<size_t>(fresh ? r : 0) * tbl_stride;
         const int nchars = wave_max_i32(fresh ? lbj : 0);
         NSM_STAT(10, 1);
         NSM_STAT(11, (nchars + 3) / 4);
@@ -502,12 +505,12 @@ __global__ __launch_bounds__(tile_max_waves(K) * kWave) NSM_TILE_OCC void indel_
       int lcsA = 0, lcsB = 0;
       build_table(pm, lstr + rA * kRow, laA);
       if (rB >= 0 && max(laA, laB) <= 2 * kWave) {
-        build_table(pm + tbl_entries, lstr + rB * kRow, laB);
+        build_table(pm + tbl_stride, lstr + rB * kRow, laB);
         // (the loops run to the longest text of a lane that can still hit)
         const int nch1 = wave_max_i32((ndA != 0xffff || ndB != 0xffff) ? lb1 : 0);
         NSM_STAT(1, 1);
         NSM_STAT(2, (nch1 + 3) / 4);
-        tile_lcs2_any<K, true>(pm, tbl_entries, text1, nch1, max(laA, laB), lcsA, lcsB, ndA, ndB, lb1);
+        tile_lcs2_any<K, true>(pm, tbl_stride, text1, nch1, max(laA, laB), lcsA, lcsB, ndA, ndB, lb1);
       } else {
         lcsA = tile_lcs1_any<K>(pm, text1, kWave, wave_max_i32(ndA != 0xffff ? lb1 : 0), laA);
         NSM_STAT(3, rB >= 0 ? 2 : 1);
@@ -588,8 +591,8 @@ __global__ __launch_bounds__(tile_max_waves(K) * kWave) NSM_TILE_OCC void indel_
           }
         } else if (wideA && wideB && max(la2A, la2B) <= 2 * kWave) {
           build_table(pm, cA, la2A);
-          build_table(pm + tbl_entries, cB, la2B);
-          tile_lcs2_any<K, false>(pm, tbl_entries, text, nch, max(la2A, la2B), l2A, l2B);
+          build_table(pm + tbl_stride, cB, la2B);
+          tile_lcs2_any<K, false>(pm, tbl_stride, text, nch, max(la2A, la2B), l2A, l2B);
           NSM_STAT(5, 1);
           NSM_STAT(6, (nch + 3) / 4);
         } else {

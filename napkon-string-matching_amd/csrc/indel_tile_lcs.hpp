@@ -8,6 +8,10 @@ namespace nsm {
 constexpr int kTileBatch = 4;   // left rows staged together
 constexpr int kTileTables = 4;  // mask tables per wave: the scan uses two (two rows per pass), the dense pass one per batch row
 constexpr int kTileHead = 12;   // dwords per head: histogram (8) | la | level row | levels | first row
+#ifndef NSM_TILE_TBL_SKEW
+#define NSM_TILE_TBL_SKEW 0
+#endif
+constexpr int kTileTableSkew = NSM_TILE_TBL_SKEW;  // u64 words between the end of one mask table of a wave and the next
 // 64-bit words per mask-table entry: K + 1, as in indel_wide.hpp -- at a stride of 2 (K + 1) dwords the 64-bit words of
 // 32 symbols fall on 32 distinct bank pairs, so a ds_read_b64 of one word for 64 lanes is conflict-free.  (Tried: 16-byte
 // aligned entries of 2 / 6 / 10 words, so that four limbs come with one ds_read_b128 -- only 16 symbols are then on
@@ -82,6 +86,29 @@ __device__ __forceinline__ int limb_zeros(const uint32_t (&v)[L]) {
   return 32 * L - ones;
 }
 
+// L limbs of a table entry.  The 64-bit words are read with VOLATILE loads so that the compiler keeps them as single
+// ds_read_b64 (2 LDS cycles each for 64 lanes): left alone it fuses two of them into one ds_read2_b64, which the LDS
+// serves at HALF the rate (8 cycles: MI355X_MICROARCH.md, LDS table) -- and these loops live on LDS bandwidth (§4.0).
+template <int L>
+__device__ __forceinline__ void load_limbs(const uint32_t* e, uint32_t (&m)[L]) {
+#ifdef NSM_TILE_PLAIN_LOADS  // (A/B builds)
+#pragma unroll
+  for (int k = 0; k < L; ++k) m[k] = e[k];
+#else
+  // (mask tables always live in LDS: the explicit address space keeps the volatile loads ds_read, not flat_load)
+  using lds_u64 = const volatile __attribute__((address_space(3))) unsigned long long;
+  using lds_u32 = const volatile __attribute__((address_space(3))) uint32_t;
+  lds_u64* e64 = (lds_u64*)(e);
+#pragma unroll
+  for (int k = 0; k + 1 < L; k += 2) {
+    const unsigned long long w = e64[k >> 1];
+    m[k] = static_cast<uint32_t>(w);
+    m[k + 1] = static_cast<uint32_t>(w >> 32);
+  }
+  if constexpr (L & 1) m[L - 1] = ((lds_u32*)(e))[L - 1];
+#endif
+}
+
 // LCS of ONE pattern (masks at `pm`: kTileWords<K> 64-bit words per symbol, the first L limbs live) and the lane's text:
 // dword w of the text is text[w * ts].  `pm`, `text` and `ts` may differ per lane (dense pass: an image column, ts = 64;
 // a row in global memory, ts = 1).
@@ -99,9 +126,7 @@ __device__ __forceinline__ int tile_lcs1(const unsigned long long* pm, const uin
     uint32_t m[4][L];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      const uint32_t* e = reinterpret_cast<const uint32_t*>(pm + ((word >> (8 * b)) & 0xffu) * kTileWords<K>);
-#pragma unroll
-      for (int k = 0; k < L; ++k) m[b][k] = e[k];
+      load_limbs<L>(reinterpret_cast<const uint32_t*>(pm + ((word >> (8 * b)) & 0xffu) * kTileWords<K>), m[b]);
     }
 #pragma unroll
     for (int b = 0; b < 4; ++b) limb_step<L>(v, m[b]);
@@ -143,13 +168,8 @@ __device__ __forceinline__ void tile_lcs2(const unsigned long long* pmA, int tbl
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const int off = static_cast<int>((word >> (8 * b)) & 0xffu) * kTileWords<K>;
-      const uint32_t* ea = reinterpret_cast<const uint32_t*>(pmA + off);
-      const uint32_t* eb = reinterpret_cast<const uint32_t*>(pmB + off);
-#pragma unroll
-      for (int k = 0; k < L; ++k) {
-        ma[b][k] = ea[k];
-        mb[b][k] = eb[k];
-      }
+      load_limbs<L>(reinterpret_cast<const uint32_t*>(pmA + off), ma[b]);
+      load_limbs<L>(reinterpret_cast<const uint32_t*>(pmB + off), mb[b]);
     }
 #pragma unroll
     for (int b = 0; b < 4; ++b) {

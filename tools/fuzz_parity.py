@@ -80,10 +80,35 @@ def main():
             print(json.dumps({"progress": counts, "round_seed": rnd}), flush=True)
             next_report += 60.0
         rng = random.Random(rnd)
-        family = rng.choice(["jaccard_raw", "indel_raw", "jaccard_levels", "indel_levels"])
+        family = rng.choice(["jaccard_raw", "indel_raw", "jaccard_levels", "indel_levels", "indel_levels", "wide"])
         counts[family] = counts.get(family, 0) + 1
         thr = rng.choice(thresholds)
         n, m = rng.randint(1, 400), rng.randint(1, 600)
+        if family == "wide":
+            # operands beyond the fast kernels through the plugin faces (only the wide items leave the fast path)
+            from napkon_string_matching_amd.compare import score_functions as sf
+
+            n, m = rng.randint(1, 60), rng.randint(1, 90)
+            if rng.random() < 0.5:
+                vocab = rng.choice([150, 3000])
+                size = lambda: rng.randint(65, 140) if rng.random() < 0.15 else rng.randint(1, 40)
+                left = [rng.sample(range(vocab), min(vocab, size())) for _ in range(n)]
+                right = [rng.sample(range(vocab), min(vocab, size())) for _ in range(m)]
+                dup_some(rng, left, right, 0.1, lambda r: list(dict.fromkeys(r[: max(1, len(r) - rng.randint(0, 3))] + [rng.randrange(vocab)])))
+                want = native.jaccard_raw(native.csr([sorted(set(r)) for r in left]), native.csr([sorted(set(r)) for r in right]), thr,
+                                          cap=1 << 16)
+                names = lambda rows: [[f"t{v}" for v in r] for r in rows]
+                check(sf.intersection_vs_union.raw_grid(names(left), names(right), thr), want, f"wide jaccard_raw vocab={vocab} thr={thr} {n}x{m}")
+            else:
+                alphabet = rng.choice(["abcdefgh ", "".join(chr(0x4E00 + k) for k in range(rng.choice([40, 300, 600])))])
+                length = lambda: rng.randint(513, 1400) if rng.random() < 0.1 else rng.randint(0, 80)
+                left = [rand_string(rng, alphabet, 0, length()) for _ in range(n)]
+                right = [rand_string(rng, alphabet, 0, length()) for _ in range(m)]
+                dup_some(rng, left, right, 0.1, lambda s_: ("".join(s_)[:-1] + rng.choice(alphabet)).strip())
+                cp = lambda ss: native.csr([[ord(c) for c in sf.fuzzy_operand(s_)] for s_ in ss])
+                want = native.indel_raw(cp(left), cp(right), thr, cap=1 << 16)
+                check(sf.fuzzy_match.raw_grid(left, right, thr), want, f"wide indel_raw |alphabet|={len(alphabet)} thr={thr} {n}x{m}")
+            continue
         if family == "jaccard_raw":
             width = rng.choice([16, 16, 32, 64])
             # the inverted-index kernel (low thresholds) on request too, and with several chunks of left rows per block
@@ -159,9 +184,11 @@ def main():
                 rt = tables.SetTable.from_levels(right, "right", dev, vocabulary, width=width, categories=rcat, category_mode=mode,
                                                  partition=partition)
                 want = native.levels(False, left, right, thr, lcat, rcat, mode, cap=1 << 19)
-                check(grid.jaccard_levels_grid(lt, rt, thr, category_mode=mode), want,
+                # the inverted-index kernel forced / forbidden / chosen by the library (W <= 32, positive thresholds)
+                index = rng.choice([None, True, False]) if (width <= 32 and thr > 0) else None
+                check(grid.jaccard_levels_grid(lt, rt, thr, category_mode=mode, index=index), want,
                       f"jaccard_levels vocab={vocab} levels<={max_levels} new<={max_new} W={width} thr={thr} mode={mode} "
-                      f"partition={partition} ncat={ncat} {n}x{m}")
+                      f"partition={partition} ncat={ncat} index={index} {n}x{m}")
             else:
                 n, m = min(n, 120), min(m, 200)
                 lcat, rcat = lcat[:n], rcat[:m]
@@ -181,9 +208,12 @@ def main():
                 li, ls, ri, rs = tables.encode_level_strings(left, right, dev, lcat, rcat, mode, partition=partition)
                 cps = lambda items: [[[ord(c) for c in s] for s in it] for it in items]
                 want = native.levels(True, cps(left), cps(right), thr, lcat, rcat, mode, cap=1 << 18)
-                check(grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode), want,
+                # multi-word strings: the shared-tile kernel (default) or the round-2 park kernel
+                park = ls.stride > 64 and rng.random() < 0.25
+                prune = rng.random() < 0.8
+                check(grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, park=park, prune=prune), want,
                       f"indel_levels hi={hi} |alphabet|={len(alphabet)} levels<={max_levels} thr={thr} mode={mode} "
-                      f"partition={partition} ncat={ncat} {n}x{m}")
+                      f"partition={partition} ncat={ncat} park={park} prune={prune} stride={ls.stride} {n}x{m}")
     print(json.dumps({"ok": True, "rounds": counts, "oracle_hits_compared": total_hits, "seconds": args.seconds,
                       "first_seed": args.seed + 1, "last_seed": rnd}))
 
