@@ -16,6 +16,13 @@ namespace nsm {
 
 constexpr uint16_t kNeverWide = 0xffff;
 
+// One 64-bit word of a mask table in LDS, as a VOLATILE load: the compiler then keeps it a single ds_read_b64 (2 LDS
+// cycles for 64 lanes) instead of fusing two into a ds_read2_b64, which the LDS serves at half the rate
+// (MI355X_MICROARCH.md, LDS table; round 3: the shared-tile levels kernel went from 51.1 to 42.0 ms with this alone).
+__device__ __forceinline__ unsigned long long lds_word(const unsigned long long* p) {
+  return *(const volatile __attribute__((address_space(3))) unsigned long long*)(p);
+}
+
 // 64-bit words per mask-table entry.  K > 1: one word of padding, so that the entries of different symbols
 // start in different LDS banks (entry stride (K + 1) * 2 dwords: 32 symbols without a conflict; at stride
 // 2 K dwords symbols c and c + 32 / K collide -- measured on Term-like strings: 62 % of the LDS cycles of the
@@ -131,7 +138,7 @@ __device__ __forceinline__ int wide_lcs_words(const unsigned long long* pm, cons
     for (int b = 0; b < 4; ++b) {
       const unsigned long long* e = pm + ((word >> (8 * b)) & 0xffu) * kPmWords<K>;
 #pragma unroll
-      for (int k = 0; k < W; ++k) m[b][k] = e[k];
+      for (int k = 0; k < W; ++k) m[b][k] = lds_word(e + k);
     }
   };
   uint32_t w_next = text[lane];                            // dword of iteration 0
@@ -207,8 +214,8 @@ __device__ __forceinline__ void wide_lcs2_words(const unsigned long long* pmA, c
       const int off = static_cast<int>((word >> (8 * b)) & 0xffu) * kPmWords<K>;
 #pragma unroll
       for (int k = 0; k < W; ++k) {
-        ma[b][k] = pmA[off + k];
-        mb[b][k] = pmB[off + k];
+        ma[b][k] = lds_word(pmA + off + k);
+        mb[b][k] = lds_word(pmB + off + k);
       }
     }
 #pragma unroll
