@@ -390,6 +390,9 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
     q.cat_mode = category_mode;
     q.threshold = threshold;
     q.use_hist = ((flags & NSM_FLAG_PRUNE) && left_strings->hist && right_strings->hist) ? 1 : 0;
+    // the histogram bound of the step-1 pair (8 more v_sad_u8 per pair) only kills whole rows at high thresholds
+    // (term, 20k x 20k: 10.50 -> 9.90 ms at 0.7, 21.2 -> 21.3 at 0.6, 41.6 -> 41.9 at 0.5)
+    q.use_h1 = (q.use_hist && threshold >= 0.65) ? 1 : 0;
     q.pm_stride = (left_strings->alphabet + 1 + 7) / 8 * 8;
 #ifndef NSM_TILE_PARK_MAX
 #define NSM_TILE_PARK_MAX 24

@@ -638,6 +638,24 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
           __builtin_amdgcn_wave_barrier();
           asm volatile("" : "+v"(lowmask), "+v"(sh16));
           uint32_t va = ~0u, vb = ~0u;
+#ifdef NSM_PARK_GROUP4  // (A/B builds: 4 code units per group -- less padding past the longest text, more branches)
+#pragma unroll
+          for (int g = 0; g < 16; ++g) {
+            if (g * 4 < nchars) {
+              unsigned long long m[4];
+#pragma unroll
+              for (int q = 0; q < 2; ++q) {
+                m[2 * q] = lev_lds_load<unsigned long long>(taddr[2 * g + q] & lowmask);
+                m[2 * q + 1] = lev_lds_load<unsigned long long>(taddr[2 * g + q] >> sh16);
+              }
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                va = lcs_step32(va, static_cast<uint32_t>(m[q]));
+                vb = lcs_step32(vb, static_cast<uint32_t>(m[q] >> 32));
+              }
+            }
+          }
+#else
 #pragma unroll
           for (int g = 0; g < 8; ++g) {
             if (g * 8 < nchars) {
@@ -654,6 +672,7 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
               }
             }
           }
+#endif
           after_lcs(r, la, 32 - __popc(va));
           after_lcs(r2, la2, 32 - __popc(vb));
           continue;

@@ -39,6 +39,7 @@ struct TileParams {
   int32_t pm_stride;      // match-mask entries per table: alphabet + 1 rounded up to 8
   int32_t cat_mode;
   int32_t use_hist;       // both string tables carry histograms and NSM_FLAG_PRUNE is set
+  int32_t use_h1;         // step-1 pre-filter: histogram bound of the step-1 pair itself (else lengths only)
   int32_t n_img;          // resident text images = steps whose right level string is in LDS (>= 2)
   int32_t park_max;       // park a row's survivors when at most this many of the 64 lanes are alive
   int32_t park_slots;     // capacity of a wave's park: kTileBatch * park_max (a row parks at most once, <= park_max pairs)
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(tile_max_waves(K) * kWave) NSM_TILE_OCC void indel_
         la[t] = static_cast<int>(rec[t * kTileHead + NB]);
         lb_t[t] = s_rlen[t * kWave + lane];
         l1[t] = 0u;
-        if (use_hist && t > 0) {
+        if (use_hist && (t > 0 || p.use_h1)) {  // (t == 0: the histogram bound of the step-1 pair itself, >= |la - lb|)
           uint32_t hl[NB], hb[NB];
 #pragma unroll
           for (int q = 0; q < NB; ++q) {
