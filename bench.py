@@ -77,6 +77,8 @@ def parse_args():
     ap.add_argument("--id-range", type=int, default=0, help="c2 / c4: draw token ids from [0, N) instead of 2^17 (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", type=int, default=0, help="1: replay each step as one captured hipGraph")
+    ap.add_argument("--serial-sort", action="store_true",
+                    help="N = 1: order the hits on the launch stream instead of a second stream (no overlap with the next step's grid)")
     ap.add_argument("--capacity", type=int, default=1 << 13)
     ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
                     help="gloo = CPU-staged rehearsal of the N > 1 path (e.g. 2 ranks sharing one GPU)")
@@ -676,6 +678,14 @@ def run_raw(args, comm, device, name, rows=0, right_rows=0, threshold=None, step
             graphs[key] = g
         return graphs[key]
 
+    # N = 1: the hit ordering of step k runs on a second stream and overlaps the grid kernel of step k + 1 (the two steps
+    # use different hit buffers; a buffer is only reused after its ordering has finished) -- the same pipelining the
+    # N > 1 path applies to the all-gather.  Every step's full work still happens inside the timed region.
+    side = torch.cuda.Stream(device) if (world == 1 and not args.graph and not args.serial_sort) else None
+    grid_done = [torch.cuda.Event() for _ in range(2)]
+    ordered = [torch.cuda.Event() for _ in range(2)]
+    used = [False, False]
+
     def step(prune=True):
         k = step_no[0] & 1
         step_no[0] += 1
@@ -685,6 +695,18 @@ def run_raw(args, comm, device, name, rows=0, right_rows=0, threshold=None, step
             pending[k] = None
         if args.graph:
             step_graph(k, prune).replay()
+        elif side is not None:
+            main = torch.cuda.current_stream(device)
+            if used[k]:
+                main.wait_event(ordered[k])  # the buffer's previous ordering has finished
+            b.count.zero_()
+            work.launch(b, stream, prune)
+            grid_done[k].record(main)
+            side.wait_event(grid_done[k])
+            _lib.check(lib.nsm_sort_hits(b.records.data_ptr(), b.scratch.data_ptr(), b.capacity, b.count.data_ptr(),
+                                         side.cuda_stream), "nsm_sort_hits")
+            ordered[k].record(side)
+            used[k] = True
         else:
             b.count.zero_()
             work.launch(b, stream, prune)
@@ -759,6 +781,8 @@ def run_raw(args, comm, device, name, rows=0, right_rows=0, threshold=None, step
             "exchange": comm.exchange,
             "rccl_ranks_seen": comm.rccl_ranks,
             "exact_prune": True,
+            "hit_ordering": ("second stream, overlapped with the next step's grid kernel (two hit buffers)" if side is not None
+                             else "launch stream"),
             "encode_and_h2d_seconds_once": round(work.encode_h2d_seconds, 4),
         },
         "roofline": valu_roofline(work.name, work.kernel_match, work.kernel + " (exact prune on)", k_ms, 1, alg_bytes,

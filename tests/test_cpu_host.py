@@ -348,3 +348,46 @@ def test_compare_cache_decision_is_collective_gloo_world2(tmp_path):
     for p in procs:
         out, _ = p.communicate(timeout=240)
         assert p.returncode == 0, out.decode()
+
+
+def test_wide_item_routing_cpu():
+    """napkon_string_matching_amd/wide.py: which items leave the fast kernels, and that the three sub-grids
+    (regular x regular, wide x all, regular x wide) together cover every pair exactly once, merged in canonical order."""
+    from napkon_string_matching_amd import grid, wide
+
+    long_s = "x" * 600
+    items_l = [["ab", "ab cd"], [long_s], ["ef"]]
+    items_r = [["gh"], ["ab", long_s + "y"], ["ij"], ["kl"]]
+    wl, wr = wide.wide_string_items(items_l, items_r)
+    assert wl.tolist() == [False, True, False] and wr.tolist() == [False, True, False, False]
+    assert wide.wide_string_items([["ab"]], [["cd"]]) is None
+    # more than 255 distinct code units: the items holding one of the rarest symbols become wide
+    many = "".join(chr(0x4E00 + k) for k in range(300))
+    wl, wr = wide.wide_string_items([["aaaa " * 50], [many]], [["aaaa"]])
+    assert wl.tolist() == [False, True] and wr.tolist() == [False]
+    sets_l = [[["t%d" % k for k in range(70)]], [["a", "b"]]]
+    sets_r = [[["a"]], [["t%d" % k for k in range(10)] * 9]]  # 90 tokens, 10 distinct: not wide
+    wl, wr = wide.wide_set_items(sets_l, sets_r)
+    assert wl.tolist() == [True, False] and wr.tolist() == [False, False]
+
+    seen = []
+
+    def fake(tag):
+        def run(li, ri):
+            li, ri = list(li), list(ri)
+            seen.extend((tag, int(a), int(b)) for a in li for b in ri)
+            n = len(li) * len(ri)
+            i = np.repeat(np.arange(len(li)), len(ri)).astype(np.int32)
+            j = np.tile(np.arange(len(ri)), len(li)).astype(np.int32)
+            score = np.array([1.0 / (1 + li[a] + 10 * ri[b]) for a, b in zip(i, j)], dtype=np.float64)
+            return grid.Hits(score, i, j) if n else grid.Hits(np.zeros(0), np.zeros(0, np.int32), np.zeros(0, np.int32))
+        return run
+
+    wl, wr = np.array([False, True, False, True]), np.array([True, False, False])
+    hits = wide.split_grid(wl, wr, fake("fast"), fake("any"))
+    pairs = sorted((a, b) for _, a, b in seen)
+    assert pairs == [(a, b) for a in range(4) for b in range(3)]  # every pair once
+    assert {t for t, a, b in seen if not wl[a] and not wr[b]} == {"fast"}
+    assert {t for t, a, b in seen if wl[a] or wr[b]} == {"any"}
+    want = sorted(((1.0 / (1 + a + 10 * b), a, b) for a in range(4) for b in range(3)), key=lambda h: (-h[0], h[1], h[2]))
+    assert hits.as_tuples() == want
