@@ -23,8 +23,12 @@
  *   - return value: 0 on success, otherwise a hipError_t or one of the NSM_E_* codes below;
  *     nsm_last_error() gives a thread-local message;
  *   - data errors that the reference raises as Python exceptions (empty-vs-empty Jaccard ->
- *     ZeroDivisionError, zero-level item -> IndexError) depend only on per-item properties and are
- *     detected by the host BEFORE the launch; the kernels define those pairs as "no hit";
+ *     ZeroDivisionError, zero-level item against an item with levels -> IndexError) depend only on
+ *     per-item properties and are detected by the host BEFORE the launch; the kernels define those pairs
+ *     as "no hit".  Two items WITHOUT levels score 0 in the reference (types/comparable_data.py:255-258):
+ *     the Python host scores such pairs itself and never passes zero-level items down; of the kernels the
+ *     multi-word fuzzy levels grid, the wave-wide one and the nsm_*_any_grid entries report them (score 0,
+ *     a hit when 0 >= threshold); a caller of the ONE-WORD fuzzy levels grid must leave zero-level items out;
  *   - hits are appended with one atomic counter; *hit_count keeps counting past `capacity`
  *     (records beyond it are dropped) so the caller can re-run with a larger buffer.
  */

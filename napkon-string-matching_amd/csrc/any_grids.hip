@@ -67,8 +67,14 @@ __global__ __launch_bounds__(kWave) void indel_any_kernel(
     bool ok = valid;
     if (p.cat_mode != NSM_CAT_NONE) ok = ok && category_match(lcat[i], catr, p.cat_mode);
     if (!__any(ok)) continue;
-    // zero-level items never hit (the host raises the reference's IndexError before the launch)
-    ok = ok && ll > 0 && lr > 0;
+    // items without levels (types/comparable_data.py:255-258): two of them score 0 (a hit when 0 >= threshold); one
+    // against an item with levels is the reference's IndexError, raised by the host before the launch: no hit here
+    if (ll == 0) {
+      if (__any(ok && lr == 0 && 0.0 >= p.threshold))
+        emit_hits_wave(hits, p.cap, count, ok && lr == 0 && 0.0 >= p.threshold, 0.0, lorig[i], rorig[jc]);
+      continue;
+    }
+    ok = ok && lr > 0;
     const int S = p.raw ? 1 : max(ll, lr);
     const int s_hi = p.raw ? 1 : max(ll, lr_max);
     double score = 0.0, ratio = 0.0, factor = 1.0;
@@ -162,7 +168,12 @@ __global__ __launch_bounds__(kWave) void jaccard_any_kernel(
     bool ok = valid;
     if (p.cat_mode != NSM_CAT_NONE) ok = ok && category_match(lcat[i], catr, p.cat_mode);
     if (!__any(ok)) continue;
-    ok = ok && ll > 0 && lr > 0;
+    if (ll == 0) {  // (as in indel_any_kernel: (0, 0) pairs score 0, mixed pairs never hit)
+      if (__any(ok && lr == 0 && 0.0 >= p.threshold))
+        emit_hits_wave(hits, p.cap, count, ok && lr == 0 && 0.0 >= p.threshold, 0.0, lorig[i], rorig[jc]);
+      continue;
+    }
+    ok = ok && lr > 0;
     const long long la0 = loff[i];
     const int na = static_cast<int>(loff[i + 1] - la0);
     const int S = p.raw ? 1 : max(ll, lr);

@@ -387,6 +387,8 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
     TileParams q;
     q.n_left = left->n; q.n_right = right->n; q.cap = capacity;
     q.n_tiles = n_tiles;
+    q.n_lstr = left_strings->n > 0 ? left_strings->n : 1;
+    q.n_rstr = right_strings->n > 0 ? right_strings->n : 1;
     q.cat_mode = category_mode;
     q.threshold = threshold;
     q.use_hist = ((flags & NSM_FLAG_PRUNE) && left_strings->hist && right_strings->hist) ? 1 : 0;

@@ -7,24 +7,27 @@
 //
 // Why this shape (round 3).  The park kernel (indel_levels_park.hpp) gives every wavefront its own right tile, so
 // every wavefront needs its own LDS image of its 64 texts: 16 KB per wave at 256 code units, which caps a CU at
-// six waves (1.5 per SIMD) -- and the multi-word recurrence is a long dependent chain of LDS reads and carry adds
-// that only occupancy hides (profiles/r02_term_sq_pmc.txt: VALU issue 0.32, 55 % of the wave-cycles waiting).
-// Here ALL the waves of a block share ONE right tile of 64 items and divide the LEFT rows among themselves:
+// six waves (1.5 per SIMD), and it re-stages texts and gathers level strings from global memory (95.7 GB of traffic
+// per launch of the term bench).  Here ALL the waves of a block share ONE right tile of 64 items and divide the LEFT
+// rows among themselves:
 //
-//   images   the level strings the tile's items use at steps 1 .. n_img, one LDS image per step, staged once per
-//            block and read by every wave ([dword][lane] layout, conflict-free).  12-16 waves share 48-64 KB
-//            instead of paying 16 KB each: 3-4 waves per SIMD.  Because the images of ALL steps stay resident, a
-//            row can be carried through its steps one after the other (row-major) without re-staging texts;
+//   images   the level strings the tile's items use at steps 1 .. n_img (3 at K = 4), one LDS image per step, staged
+//            once per block and read by every wave ([dword][lane] layout, conflict-free), with their lengths and
+//            histograms.  One block per CU (all 160 KB): 11 waves at K = 4.  Because the images of ALL steps stay
+//            resident, a row is carried through its steps one after the other (row-major) without re-staging texts;
 //   scan     per batch of 4 left rows a wave stages their heads (lengths, histograms) and their step-1 / step-2
 //            level strings in one go, then scores TWO rows per pass (two mask tables, one text read, two
-//            independent carry chains).  After every step the histogram bound of the next level pair decides which
-//            lanes are still alive; a row with many survivors goes on wave-wide, a row with few parks them;
-//   dense    the wave's OWN park (no block barrier, no atomics): lane = one pair, its text is a COLUMN of the
-//            resident image (no gather from global memory), mask tables of the batch's rows side by side.
+//            independent carry chains) on 32-bit limbs (indel_tile_lcs.hpp).  After every step the histogram bound
+//            of the next level pair decides which lanes are still alive; a row with more than park_max survivors
+//            goes on wave-wide at the next step's image, fewer are parked;
+//   dense    the wave's OWN park (no block barrier, no atomics), drained after every batch: lane = one pair, its
+//            text is a COLUMN of the resident image (no gather from global memory), one mask table per batch row;
+//   balance  batches come from a block-shared counter; blocks are dealt to the XCDs so that each XCD walks the tiles
+//            x, x + 8, ... slice-major (same left slice in its L2, same mix of long and short strings everywhere).
 //
-// Steps whose right level is not resident (items deeper than n_img + 1 levels, rare) read their text from global
-// memory in the dense pass.  Every test that drops a pair is an upper bound: hits are identical to the wave-wide
-// kernel's and the oracle's.
+// Steps whose right level is not resident (items deeper than n_img + 1 levels) read their text from global memory.
+// Every test that drops a pair is an upper bound: hits are identical to the wave-wide kernel's and the oracle's.
+// Measurements, and what was tried and dropped: DESIGN.md section 4.4.
 #pragma once
 #include "indel_tile_lcs.hpp"
 
@@ -34,6 +37,8 @@ struct TileParams {
   int32_t n_left;
   int32_t n_right;
   int32_t n_tiles;
+  int32_t n_lstr;         // rows of the left / right string tables: a zero-level item's `first` may point one past the end
+  int32_t n_rstr;
   int32_t y_slices;       // grid = n_tiles * y_slices blocks (linear: the kernel maps them XCD-aware)
   int32_t rows_per_slice; // unpartitioned tables: left rows per slice
   int32_t pm_stride;      // match-mask entries per table: alphabet + 1 rounded up to 8
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(tile_max_waves(K) * kWave) NSM_TILE_OCC void indel_
 
   // ---- the lane's right item; per step t + 1 (t < 3) the level string's length and histogram in registers (H phase)
   const int lr = rnlev[jc];
-  const int rrow0 = rfirst[jc];
+  const int rrow0 = min(rfirst[jc], p.n_rstr - 1);  // (a trailing zero-level item points one past the table)
   const int jorig = rorig[jc];
   const uint64_t catr = (p.cat_mode != NSM_CAT_NONE) ? rcat[jc] : 0ull;
   // ---- block setup: images, right-side tables, weights
@@ -395,13 +400,15 @@ __global__ __launch_bounds__(tile_max_waves(K) * kWave) NSM_TILE_OCC void indel_
   // ---- this wave's tile against the batch rows [ib, ib + nrows); okbits bit r = the lane passes the category
   // predicate for row ib + r
   auto scan_batch = [&](int ib, int nrows, uint32_t okbits, uint32_t rows_ok) __attribute__((always_inline)) {
+    const uint32_t okbits_all = okbits;  // category predicate of every lane (zero-level right items included)
+    auto zero_ok = [&](int r) -> bool { return ((okbits_all >> r) & 1u) != 0u; };
     cur_ib = ib;
     cur_nrows = nrows;
     NSM_STAT(0, 1);
     // ---- stage: (levels, first row) of the batch's rows, then heads and the level strings of steps 1 and 2
     {
       const int i = min(ib + (lane & (kBatch - 1)), p.n_left - 1);
-      const int ll = lnlev[i], lf = lfirst[i];
+      const int ll = lnlev[i], lf = min(lfirst[i], p.n_lstr - 1);  // (a trailing zero-level item points one past the table)
       if (lane < kBatch) {
         srow[2 * lane] = ll;
         srow[2 * lane + 1] = lf;
@@ -439,6 +446,20 @@ __global__ __launch_bounds__(tile_max_waves(K) * kWave) NSM_TILE_OCC void indel_
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
+
+    // ---- zero-level items (types/comparable_data.py:255-258: two items without levels score 0, one without levels
+    // against one with levels is the reference's IndexError, which the host raises before the launch): no step runs
+    // for them.  A (0, 0) pair is a hit exactly when 0 >= threshold.
+    okbits = lr > 0 ? okbits : 0u;
+    for (uint32_t rows = rows_ok; rows;) {
+      const int r = __builtin_ctz(rows);
+      rows &= rows - 1;
+      if (head_ll(r) > 0) continue;
+      rows_ok &= ~(1u << r);
+      const bool hit00 = valid && lr == 0 && 0.0 >= p.threshold && zero_ok(r);
+      emit_hits_wave(hits, p.cap, count, hit00, 0.0, lorig[ib + r], jorig);
+    }
+    rows_ok = __any(okbits != 0u) ? rows_ok : 0u;
 
     // ---- H: the smallest step-1 LCS that keeps the pair (row r, lane) alive; 0xffff = cannot hit
     auto need_of = [&](int r) -> int {

@@ -498,9 +498,32 @@ def test_indel_levels_term_like(dev, entries, words, n_left, n_right, stride):
     cps = lambda items: [[[ord(c) for c in s] for s in it] for it in items]
     every = native.levels(True, cps(left), cps(right), 0.0, None, None, 0, cap=n_left * n_right)
     assert len(every) == n_left * n_right
+    # items WITHOUT levels, in a category of their own on both sides (types/comparable_data.py:255-258: two such items
+    # score 0 -- a hit exactly when the threshold is <= 0; against an item with levels the reference raises IndexError,
+    # which the host checks before the launch, so the category filter must keep them apart here).  The last left item is
+    # one of them: its first level row points one past the string table.
+    zl, zr = [n_left - 1, 11], [n_right - 1, 13]
+    for k in zl:
+        left[k], lcat[k] = [], np.uint64(1 << 40)
+    for k in zr:
+        right[k], rcat[k] = [], np.uint64(1 << 40)
+    every = [(s_, i, j) for (s_, i, j) in every if i not in zl and j not in zr] + [(0.0, i, j) for i in zl for j in zr]
+    every.sort(key=lambda h: (-h[0], h[1], h[2]))
     for mode, partition in ((_lib.CAT_NONE, True), (_lib.CAT_INTERSECT, True), (_lib.CAT_INTERSECT_OR_BOTH_EMPTY, False)):
         li, ls, ri, rs = tables.encode_level_strings(left, right, dev, lcat, rcat, mode, partition=partition)
         assert ls.stride == rs.stride == stride
+        if mode == _lib.CAT_NONE:  # (no category filter: the zero-level items would meet items with levels)
+            drop_l, drop_r = set(zl), set(zr)
+            l2 = [it for k, it in enumerate(left) if k not in drop_l]
+            r2 = [it for k, it in enumerate(right) if k not in drop_r]
+            li, ls, ri, rs = tables.encode_level_strings(l2, r2, dev)
+            lmap = [k for k in range(n_left) if k not in drop_l]
+            rmap = [k for k in range(n_right) if k not in drop_r]
+            for thr in (0.0, 0.45, 0.7):
+                want = [(s_, i, j) for (s_, i, j) in every if s_ >= thr and i not in drop_l and j not in drop_r]
+                got = [(s_, lmap[i], rmap[j]) for (s_, i, j) in grid.indel_levels_grid(li, ls, ri, rs, thr, capacity=1 << 17).as_tuples()]
+                assert sorted(got, key=lambda h: (-h[0], h[1], h[2])) == want
+            continue
         if mode == _lib.CAT_NONE:
             keep = lambda i, j: True
         elif mode == _lib.CAT_INTERSECT:
