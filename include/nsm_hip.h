@@ -26,9 +26,10 @@
  *     ZeroDivisionError, zero-level item against an item with levels -> IndexError) depend only on
  *     per-item properties and are detected by the host BEFORE the launch; the kernels define those pairs
  *     as "no hit".  Two items WITHOUT levels score 0 in the reference (types/comparable_data.py:255-258):
- *     the Python host scores such pairs itself and never passes zero-level items down; of the kernels the
- *     multi-word fuzzy levels grid, the wave-wide one and the nsm_*_any_grid entries report them (score 0,
- *     a hit when 0 >= threshold); a caller of the ONE-WORD fuzzy levels grid must leave zero-level items out;
+ *     the Python host scores such pairs itself and never passes zero-level items down, and a caller of the
+ *     levels grids must do the same (the one-word kernel and the NSM_FLAG_PARK / NSM_FLAG_WAVE_WIDE variants
+ *     stage a row's strings before they look at its depth).  The multi-word fuzzy levels kernel and the
+ *     nsm_*_any_grid entries do take them: such a pair is reported with score 0 when 0 >= threshold;
  *   - hits are appended with one atomic counter; *hit_count keeps counting past `capacity`
  *     (records beyond it are dropped) so the caller can re-run with a larger buffer.
  */

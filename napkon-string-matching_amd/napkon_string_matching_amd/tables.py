@@ -601,7 +601,9 @@ class StrTable:
         n, stride = codes.shape
         dev = torch.device(device)
         new = lambda shape, dtype: torch.empty(shape, dtype=dtype, device=dev)
-        cap = max(n, 1)  # (an empty tensor has no data pointer)
+        # one spare row: an item without levels that closes the items table points one row past the strings, and the
+        # one-word levels kernel stages the heads of every row of a batch before it knows the row's depth
+        cap = n + 1
         t = cls(codes=new((cap, stride), torch.uint8), len=new(cap, torch.int32),
                 orig=new(cap, torch.int32), n=n, stride=stride, alphabet=alphabet,
                 has_empty=bool(n and int(lengths.min()) == 0), hist=new((cap, 32), torch.uint8),

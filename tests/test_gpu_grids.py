@@ -536,8 +536,18 @@ def test_indel_levels_term_like(dev, entries, words, n_left, n_right, stride):
             _same_hits(got, want)
             assert thr > 0.8 or len(want) > 0
             if thr in (0.2, 0.7):
-                _same_hits(grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, capacity=1 << 17, park=True), want)
                 _same_hits(grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, capacity=1 << 17, prune=False), want)
+    # the round-1 / round-2 kernels behind NSM_FLAG_WAVE_WIDE / NSM_FLAG_PARK do not take items without levels
+    # (include/nsm_hip.h; the Python host never passes them down): compared on the grid without them
+    keep_l = [k for k in range(n_left) if k not in zl]
+    keep_r = [k for k in range(n_right) if k not in zr]
+    li, ls, ri, rs = tables.encode_level_strings([left[k] for k in keep_l], [right[k] for k in keep_r], dev,
+                                                 lcat[keep_l], rcat[keep_r], _lib.CAT_INTERSECT)
+    for thr in (0.2, 0.7):
+        tile = grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=_lib.CAT_INTERSECT, capacity=1 << 17)
+        park = grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=_lib.CAT_INTERSECT, capacity=1 << 17, park=True)
+        wide = grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=_lib.CAT_INTERSECT, capacity=1 << 17, wave_wide=True)
+        assert tile.as_tuples() == park.as_tuples() == wide.as_tuples() and (thr > 0.5 or len(tile) > 0)
 
 
 @pytest.mark.parametrize("vocab", [20_000, 1 << 17])
