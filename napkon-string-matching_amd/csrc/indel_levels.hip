@@ -493,6 +493,7 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
 #endif
     q.park_slots = K >= 4 ? NSM_PARK_SLOTS_WIDE : 128;  // per region (park_sub(K) regions); 64 overflow on Term-like strings (140 -> 157 ms)
     q.park_max = NSM_PARK_MAX;
+    q.xcd_slices = 0;
     q.rows_per_chunk = p.rows_per_chunk;
     const size_t tbl_bytes = static_cast<size_t>(q.pm_stride) * pm_words * 8;
     const size_t fixed_wave = (K > 1 ? 16 * K * kWave * 4 + batch * kWave * 8 : 0) + batch * kWave * 2 +
@@ -526,13 +527,22 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
       if (slices > 1024) slices = 1024;
       while (slices < 64 && static_cast<long long>(pgrid.x) * slices < 4096) slices *= 2;
       pgrid.y = static_cast<unsigned>(slices);
+#ifndef NSM_PARK_XCD
+#define NSM_PARK_XCD 1  // (configs[4]: fuzzy grids 419.6 -> 409.1 ms; what it does to the traffic: DESIGN.md section 4.4)
+#endif
+      if (NSM_PARK_XCD) {  // 1-D grid mapped XCD-aware in the kernel (indel_levels_park.hpp); spare blocks leave at once
+        q.xcd_slices = static_cast<int>(slices);
+        const long long per_xcd = ((slices + 7) / 8) * (static_cast<long long>(pgrid.x) + 64);
+        pgrid.x = static_cast<unsigned>(8 * per_xcd);
+        pgrid.y = 1;
+      }
     }
 #define NSM_LAUNCH_PARK(KK)                                                                                       \
   hipLaunchKernelGGL((indel_levels_park_kernel<KK>), pgrid, dim3(pw * kWave), park_lds,                          \
                      static_cast<hipStream_t>(stream), left->first, left->nlev, left->orig, left->cat,           \
                      left->seg_start, left_strings->codes, left_strings->len, left_strings->hist, right->first,  \
                      right->nlev, right->orig, right->cat, right->seg, right_strings->codes, right_strings->len, \
-                     right_strings->hist, hits, hit_count, q)
+                     right_strings->hist, hits, hit_count, q, right->seg_start)
     if (K == 1) NSM_LAUNCH_PARK(1);
     else if (K == 2) NSM_LAUNCH_PARK(2);
     else if (K == 4) NSM_LAUNCH_PARK(4);

@@ -41,6 +41,7 @@ struct ParkParams {
   int32_t fin_rows;    // mask tables per wave in the dense pass (1 .. batch)
   int32_t park_slots;  // capacity of ONE park region (there are kSub)
   int32_t park_max;    // park a row's survivors when at most this many of the 64 lanes are alive
+  int32_t xcd_slices;  // > 0 (partitioned tables): 1-D grid mapped XCD-aware, this many slices per category
   double threshold;
   unsigned long long cap;
 };
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
     const int32_t* __restrict__ rnlev, const int32_t* __restrict__ rorig, const uint64_t* __restrict__ rcat,
     const int32_t* __restrict__ rseg, const uint8_t* __restrict__ rcodes, const int32_t* __restrict__ rlen,
     const uint8_t* __restrict__ rhist, nsm_hit* __restrict__ hits, unsigned long long* __restrict__ count,
-    const ParkParams p) {
+    const ParkParams p, const int32_t* __restrict__ rsegstart) {
   // LDS (dynamic, starts at offset 0 -- the one-word text images hold raw LDS addresses):
   //   per wave: [fin_rows][pm_stride * kPmWords<K>] u64 mask tables (the scan uses table 0)
   //             (K > 1) [16 K][64] u32 text image | [batch][64] u16 need (then the step-1 LCS)
@@ -160,7 +161,38 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
   int* s_valid = s_cnt + 2 * kSub;                    // [2][kSub]: slots [0, valid) are written
   const uint32_t pm_base = static_cast<uint32_t>(wave * wave_bytes);
 
-  const int tile = blockIdx.x * waves + wave;
+  // Which (tile block, left slice) this block works on.  With a category partition and p.xcd_slices > 0 the grid is 1-D
+  // and mapped XCD-aware (blocks go to the 8 XCDs round-robin, each with its own 4 MB L2): a UNIT = (category c, slice y
+  // of its left rows) is walked by the tile blocks that hold rows of c; units are dealt to the XCDs round-robin and an XCD
+  // takes its units one after the other, so the ~128 blocks resident on an XCD read one or two left slices out of its
+  // L2 instead of a dozen (x-fastest order: the resident blocks span ~11 categories, 18 MB of left rows per XCD).
+  int bx = blockIdx.x, by = blockIdx.y, ny = gridDim.y, only_cat = -1;
+  if (p.xcd_slices > 0) {
+    const int xcd = blockIdx.x & 7;
+    int k = blockIdx.x >> 3;
+    const int rows_per_tb = kWave * waves;
+    ny = p.xcd_slices;
+    bool found = false;
+    for (int c = 0; c < 64 && !found; ++c) {
+      const int r0 = rsegstart[c], r1 = rsegstart[c + 1];
+      if (r0 >= r1) continue;
+      const int first = r0 / rows_per_tb, ntb = (r1 - 1) / rows_per_tb - first + 1;
+      const int y0 = ((xcd - c * ny) % 8 + 8) % 8;  // units u = c * ny + y with u % 8 == xcd
+      if (y0 >= ny) continue;
+      const int cnt_y = (ny - y0 + 7) / 8;
+      if (k < cnt_y * ntb) {
+        const int yi = k / ntb;
+        by = y0 + 8 * yi;
+        bx = first + (k - yi * ntb);
+        only_cat = c;
+        found = true;
+      } else {
+        k -= cnt_y * ntb;
+      }
+    }
+    if (!found) return;  // (the whole block, before any barrier)
+  }
+  const int tile = bx * waves + wave;
   const int j = tile * kWave + lane;
   const bool valid = j < p.n_right;  // a whole wave may be beyond the table: it still takes part in the barriers
   const int jc = valid ? j : p.n_right - 1;
@@ -170,7 +202,7 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
   // blockIdx.y of gridDim.y of EACH of the tiles' categories' row ranges -- every block has work (a grid of
   // (tile block, row chunk) pairs is 97 % blocks that find no row of their categories and leave: 7 % of the
   // kernel's time at configs[4]'s shape).
-  const int i0 = partitioned ? 0 : blockIdx.y * p.rows_per_chunk;
+  const int i0 = partitioned ? 0 : by * p.rows_per_chunk;
   const int i1 = partitioned ? p.n_left : min(p.n_left, i0 + p.rows_per_chunk);
   const bool use_hist = p.use_hist != 0;
 
@@ -196,7 +228,8 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
     s_cats = 1ull;
   }
   __syncthreads();
-  const unsigned long long cats_block = s_cats;  // block-uniform from here on
+  // block-uniform from here on (XCD-aware mapping: this visit of the tile block only serves its unit's category)
+  const unsigned long long cats_block = only_cat >= 0 ? (s_cats & (1ull << only_cat)) : s_cats;
   // ---- the lane's right item
   const int lr = rnlev[jc];
   const int rrow0 = rfirst[jc];
@@ -902,9 +935,9 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
     int a = i0, b = i1;
     if (partitioned) {  // slice blockIdx.y of the category's rows, cut at batch boundaries
       const int lo = lsegstart[c], len = lsegstart[c + 1] - lo;
-      const int per = (((len + static_cast<int>(gridDim.y) - 1) / static_cast<int>(gridDim.y)) + kBatch - 1) / kBatch * kBatch;
-      a = lo + min(len, static_cast<int>(blockIdx.y) * per);
-      b = lo + min(len, (static_cast<int>(blockIdx.y) + 1) * per);
+      const int per = (((len + ny - 1) / ny) + kBatch - 1) / kBatch * kBatch;
+      a = lo + min(len, by * per);
+      b = lo + min(len, (by + 1) * per);
     }
     const unsigned long long lower = (1ull << c) - 1ull;
     for (int sb = a; sb < b; sb += kBatch * kSub) {
