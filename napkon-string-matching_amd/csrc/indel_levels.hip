@@ -286,7 +286,55 @@ __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
 }  // namespace nsm
 
 #include "indel_levels_park.hpp"
+#include "indel_levels_finish.hpp"
 #include "indel_levels_tile.hpp"
+
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
+
+namespace nsm {
+
+// Device workspace of the split path (survivor queue + control words), one per (device, stream), grown on demand and kept:
+// a grid call must not allocate per launch, and calls on different streams may overlap.
+struct SplitWorkspace {
+  unsigned long long* queue = nullptr;
+  unsigned long long* ctl = nullptr;  // [0] hit counter at the start | [1] overflow flag (int) | [2 ..] queue counter per round
+  unsigned long long cap = 0;
+};
+constexpr int kSplitMaxRounds = 62;
+constexpr int kSplitCtlWords = 2 + kSplitMaxRounds;
+
+static int split_workspace(void* stream, unsigned long long entries, SplitWorkspace* out) {
+  static std::mutex mu;
+  static std::map<std::pair<int, void*>, SplitWorkspace> all;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return hip_status(e, "hipGetDevice");
+  std::lock_guard<std::mutex> lock(mu);
+  SplitWorkspace& w = all[std::make_pair(dev, stream)];
+  if (!w.ctl) {
+    e = hipMalloc(reinterpret_cast<void**>(&w.ctl), kSplitCtlWords * 8);
+    if (e != hipSuccess) return hip_status(e, "hipMalloc(split control words)");
+  }
+  if (w.cap < entries) {
+    if (w.queue) {  // (launches that still read the old queue are ahead of this call in the same stream)
+      e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
+      if (e == hipSuccess) e = hipFree(w.queue);
+      w.queue = nullptr;
+      w.cap = 0;
+      if (e != hipSuccess) return hip_status(e, "hipFree(survivor queue)");
+    }
+    e = hipMalloc(reinterpret_cast<void**>(&w.queue), entries * 8);
+    if (e != hipSuccess) return hip_status(e, "hipMalloc(survivor queue)");
+    w.cap = entries;
+  }
+  *out = w;
+  return 0;
+}
+
+}  // namespace nsm
 
 #ifdef NSM_TILE_STATS
 // variant builds only: copy the tile kernel's work counters to `out[16]` and reset them (synchronises the device)
@@ -496,6 +544,21 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
     q.xcd_slices = 0;
     q.rows_per_chunk = p.rows_per_chunk;
     const size_t tbl_bytes = static_cast<size_t>(q.pm_stride) * pm_words * 8;
+    q.slice_base = 0;
+    q.slices_total = 0;
+    q.qcap = 0;
+    // Split path (one-word strings, bound on, thresholds where few pairs outlive step 1): scan kernel -> global survivor
+    // queue -> finish kernel (indel_levels_finish.hpp), the left slices in rounds sized to the queue.  A queue that
+    // overflows anyway (the survival rate is a guess) raises a flag: the hit counter is put back and the fused kernel,
+    // launched behind the rounds and gated on that flag, redoes the grid.  NSM_FLAG_PARK = the fused kernel alone.
+#ifndef NSM_SPLIT_MIN_THRESHOLD
+#define NSM_SPLIT_MIN_THRESHOLD 0.65
+#endif
+#ifndef NSM_SPLIT_QUEUE_MAX
+#define NSM_SPLIT_QUEUE_MAX (128ull << 20)  // entries (1 GB)
+#endif
+    const bool split = K == 1 && !(flags & NSM_FLAG_PARK) && q.use_hist && threshold >= NSM_SPLIT_MIN_THRESHOLD &&
+                       q.pm_stride <= 64 && left->n < (1 << kQueueRowBits) && right->n < (1 << kQueueRowBits);
     const size_t fixed_wave = (K > 1 ? 16 * K * kWave * 4 + batch * kWave * 8 : 0) + batch * kWave * 2 +
                               batch * 3 * kHeadDwords * 4 + batch * kWave * K;
     const int sub = park_sub(K);
@@ -537,12 +600,74 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
         pgrid.y = 1;
       }
     }
+    const int* gate = nullptr;
+    if (split) {
+      // rounds: the expected number of survivors (2 % of the pairs visited; a partition visits ~1/16 of the grid or less)
+      // against the queue
+      double expect = static_cast<double>(left->n) * static_cast<double>(right->n) * 0.02 * (left->seg ? 1.0 / 16 : 1.0);
+      unsigned long long qmax = NSM_SPLIT_QUEUE_MAX;
+      if (const char* env = std::getenv("NSM_SPLIT_QUEUE_CAP")) qmax = std::strtoull(env, nullptr, 10);  // (tests: force an overflow)
+      if (qmax < 1) qmax = 1;
+      const long long slices_all = left->seg ? static_cast<long long>(q.xcd_slices ? q.xcd_slices : pgrid.y) : pgrid.y;
+      long long rounds = static_cast<long long>(expect / static_cast<double>(qmax)) + 1;
+      if (rounds > kSplitMaxRounds) rounds = kSplitMaxRounds;
+      if (rounds > slices_all) rounds = slices_all;
+      unsigned long long entries = static_cast<unsigned long long>(expect / static_cast<double>(rounds)) + (1ull << 16);
+      if (entries > qmax) entries = qmax;
+      SplitWorkspace ws;
+      const int rc = split_workspace(stream, entries, &ws);
+      if (rc != 0) return rc;
+      hipStream_t hs = static_cast<hipStream_t>(stream);
+      hipLaunchKernelGGL(split_begin_kernel, dim3(1), dim3(kWave), 0, hs, ws.ctl, kSplitCtlWords, hit_count);
+      ParkParams sq = q;
+      sq.park_slots = 0;
+      sq.fin_rows = 1;
+      sq.qcap = entries;  // (not ws.cap: a smaller grid after a larger one keeps its own bound, results do not depend on history)
+      sq.slices_total = static_cast<int>(slices_all);
+      const size_t scan_lds = pw * (tbl_bytes + fixed_wave + kQueueBuf * 8) + 66 * 16 + 8 + 4 * sub * 4;
+      FinishParams fp;
+      fp.pm_stride = q.pm_stride;
+      fp.pad_code = left_strings->alphabet;
+      fp.use_hist = q.use_hist;
+      fp.threshold = threshold;
+      fp.cap = capacity;
+      fp.qcap = entries;
+      const long long per_round = (slices_all + rounds - 1) / rounds;
+      int* qflag = reinterpret_cast<int*>(ws.ctl + 1);
+      for (long long rd = 0; rd * per_round < slices_all; ++rd) {
+        const long long s0 = rd * per_round;
+        const long long ns = slices_all - s0 < per_round ? slices_all - s0 : per_round;
+        sq.slice_base = static_cast<int>(s0);
+        dim3 sgrid = pgrid;
+        if (left->seg && q.xcd_slices) {
+          sq.xcd_slices = static_cast<int>(ns);
+          const long long per_xcd = ((ns + 7) / 8) * (static_cast<long long>((n_tiles + pw - 1) / pw) + 64);
+          sgrid = dim3(static_cast<unsigned>(8 * per_xcd), 1);
+        } else {
+          sgrid.y = static_cast<unsigned>(ns);
+        }
+        hipLaunchKernelGGL((indel_levels_park_kernel<1, true>), sgrid, dim3(pw * kWave), scan_lds, hs, left->first,
+                           left->nlev, left->orig, left->cat, left->seg_start, left_strings->codes, left_strings->len,
+                           left_strings->hist, right->first, right->nlev, right->orig, right->cat, right->seg,
+                           right_strings->codes, right_strings->len, right_strings->hist, hits, hit_count, sq,
+                           right->seg_start, ws.queue, ws.ctl + 2 + rd, qflag, static_cast<const int*>(nullptr));
+        hipLaunchKernelGGL(indel_levels_finish_kernel, dim3(kFinishBlocks), dim3(kWave),
+                           static_cast<size_t>(fp.pm_stride) * 2 * kWave * 4, hs, left->first, left->nlev, left->orig,
+                           left_strings->codes, left_strings->len, left_strings->hist, right->first, right->nlev,
+                           right->orig, right_strings->codes, right_strings->len, right_strings->hist, hits, hit_count,
+                           ws.queue, ws.ctl + 2 + rd, qflag, fp);
+      }
+      hipLaunchKernelGGL(split_end_kernel, dim3(1), dim3(kWave), 0, hs, ws.ctl, hit_count);
+      gate = qflag;
+    }
+    unsigned long long* no_queue = nullptr;
+    int* no_flag = nullptr;
 #define NSM_LAUNCH_PARK(KK)                                                                                       \
   hipLaunchKernelGGL((indel_levels_park_kernel<KK>), pgrid, dim3(pw * kWave), park_lds,                          \
                      static_cast<hipStream_t>(stream), left->first, left->nlev, left->orig, left->cat,           \
                      left->seg_start, left_strings->codes, left_strings->len, left_strings->hist, right->first,  \
                      right->nlev, right->orig, right->cat, right->seg, right_strings->codes, right_strings->len, \
-                     right_strings->hist, hits, hit_count, q, right->seg_start)
+                     right_strings->hist, hits, hit_count, q, right->seg_start, no_queue, no_queue, no_flag, gate)
     if (K == 1) NSM_LAUNCH_PARK(1);
     else if (K == 2) NSM_LAUNCH_PARK(2);
     else if (K == 4) NSM_LAUNCH_PARK(4);

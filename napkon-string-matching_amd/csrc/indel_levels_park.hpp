@@ -42,9 +42,20 @@ struct ParkParams {
   int32_t park_slots;  // capacity of ONE park region (there are kSub)
   int32_t park_max;    // park a row's survivors when at most this many of the 64 lanes are alive
   int32_t xcd_slices;  // > 0 (partitioned tables): 1-D grid mapped XCD-aware, this many slices per category
+  int32_t slice_base;  // first left slice (or row chunk) of this launch: the split path walks the slices in rounds
+  int32_t slices_total;  // > 0: left slices per category over all rounds (the launch holds xcd_slices / gridDim.y of them)
   double threshold;
   unsigned long long cap;
+  unsigned long long qcap;  // (SPLIT) capacity of the survivor queue, entries
 };
+
+// Survivor queue of the split path (SPLIT = true: scan kernel here, finish kernel in indel_levels_finish.hpp): one 64-bit
+// entry per pair that is still alive after step 1 and has steps to go:  left row << 31 | right row << 7 | step-1 LCS.
+constexpr int kQueueBuf = 256;  // entries a wave collects in LDS before it reserves room in the global queue
+constexpr int kQueueRowBits = 24;
+__host__ __device__ constexpr unsigned long long queue_entry(int i, int j, int lcs) {
+  return (static_cast<unsigned long long>(i) << 31) | (static_cast<unsigned long long>(j) << 7) | static_cast<unsigned long long>(lcs);
+}
 
 constexpr int park_batch(int K) { return K >= 4 ? 4 : 8; }
 // scan batches between two block barriers, A/B-measured on C5-shaped cohorts (3 x 100k^2): 1 / 2 / 4 / 8 / 16 ->
@@ -111,7 +122,7 @@ __device__ __forceinline__ float rest_bound(int s, int S, float ub) {
 }
 
 
-template <int K>
+template <int K, bool SPLIT = false>
 __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
     const int32_t* __restrict__ lfirst, const int32_t* __restrict__ lnlev, const int32_t* __restrict__ lorig,
     const uint64_t* __restrict__ lcat, const int32_t* __restrict__ lsegstart, const uint8_t* __restrict__ lcodes,
@@ -119,7 +130,12 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
     const int32_t* __restrict__ rnlev, const int32_t* __restrict__ rorig, const uint64_t* __restrict__ rcat,
     const int32_t* __restrict__ rseg, const uint8_t* __restrict__ rcodes, const int32_t* __restrict__ rlen,
     const uint8_t* __restrict__ rhist, nsm_hit* __restrict__ hits, unsigned long long* __restrict__ count,
-    const ParkParams p, const int32_t* __restrict__ rsegstart) {
+    const ParkParams p, const int32_t* __restrict__ rsegstart, unsigned long long* __restrict__ queue,
+    unsigned long long* __restrict__ qcount, int* __restrict__ qflag, const int* __restrict__ gate) {
+  // `gate` (fused kernel only): the launch that follows the split path's rounds does nothing unless the queue overflowed
+  if constexpr (!SPLIT) {
+    if (gate != nullptr && *gate == 0) return;
+  }
   // LDS (dynamic, starts at offset 0 -- the one-word text images hold raw LDS addresses):
   //   per wave: [fin_rows][pm_stride * kPmWords<K>] u64 mask tables (the scan uses table 0)
   //             (K > 1) [16 K][64] u32 text image | [batch][64] u16 need (then the step-1 LCS)
@@ -142,7 +158,8 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
 
   const int tbl_entries = p.pm_stride * kPmWords<K>;
   const size_t wave_bytes = static_cast<size_t>(p.fin_rows) * tbl_entries * 8 + (K > 1 ? 16 * K * kWave * 4 : 0) +
-                            kBatch * kWave * 2 + (K > 1 ? kBatch * kWave * 8 : 0) + kBatch * 3 * kHeadDwords * 4 + kBatch * kRow;
+                            kBatch * kWave * 2 + (K > 1 ? kBatch * kWave * 8 : 0) + kBatch * 3 * kHeadDwords * 4 + kBatch * kRow +
+                            (SPLIT ? kQueueBuf * 8 : 0);
   unsigned char* wbase = reinterpret_cast<unsigned char*>(s_mem) + wave * wave_bytes;
   unsigned long long* pm = reinterpret_cast<unsigned long long*>(wbase);
   uint32_t* wtext = reinterpret_cast<uint32_t*>(pm + static_cast<size_t>(p.fin_rows) * tbl_entries);
@@ -150,6 +167,8 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
   double* sc = reinterpret_cast<double*>(need + kBatch * kWave);  // (K > 1) running scores of the rows that go on wave-wide
   uint32_t* head = reinterpret_cast<uint32_t*>(sc + (K > 1 ? kBatch * kWave : 0));
   uint8_t* lstr = reinterpret_cast<uint8_t*>(head + kBatch * 3 * kHeadDwords);
+  unsigned long long* qbuf = reinterpret_cast<unsigned long long*>(lstr + kBatch * kRow);  // (SPLIT) [kQueueBuf]
+  int qn = 0;  // (SPLIT, wave-uniform) entries in qbuf
   unsigned char* bbase = reinterpret_cast<unsigned char*>(s_mem) + waves * wave_bytes;
   const int park_total = p.park_slots * kSub;
   double* park_score = reinterpret_cast<double*>(bbase);
@@ -202,7 +221,7 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
   // blockIdx.y of gridDim.y of EACH of the tiles' categories' row ranges -- every block has work (a grid of
   // (tile block, row chunk) pairs is 97 % blocks that find no row of their categories and leave: 7 % of the
   // kernel's time at configs[4]'s shape).
-  const int i0 = partitioned ? 0 : by * p.rows_per_chunk;
+  const int i0 = partitioned ? 0 : (by + p.slice_base) * p.rows_per_chunk;
   const int i1 = partitioned ? p.n_left : min(p.n_left, i0 + p.rows_per_chunk);
   const bool use_hist = p.use_hist != 0;
 
@@ -284,6 +303,26 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
       return -1;
     }
     return have;
+  };
+
+  // (SPLIT) the wave's collected survivors go to the global queue: one atomic per ~200 entries.  A full queue raises the
+  // flag and drops the entries: the host side then runs the fused kernel over the whole grid (gate).
+  auto flush_queue = [&]() {
+    if (qn == 0) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(qcount, static_cast<unsigned long long>(qn));
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base));
+    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base >> 32));
+    base = (static_cast<unsigned long long>(hi) << 32) | lo;
+    if (base + static_cast<unsigned long long>(qn) > p.qcap) {
+      if (lane == 0) atomicOr(qflag, 1);
+    } else {
+      for (int t = lane; t < qn; t += kWave) queue[base + t] = qbuf[t];
+    }
+    __builtin_amdgcn_wave_barrier();
+    qn = 0;
   };
 
   // copy the level strings of step s of the rows in `rows` into the wave's LDS (lane = one dword of one row).  All
@@ -630,6 +669,14 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
       const unsigned long long who = __ballot(more);
       if (who == 0ull) return;
       const int n = __popcll(who);
+      if constexpr (SPLIT) {
+        if (more)
+          qbuf[qn + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(who >> 32),
+                                              __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(who), 0u))] = queue_entry(ib + r, jc, lcs);
+        qn += n;
+        if (qn > kQueueBuf - kWave) flush_queue();
+        return;
+      }
       int have = -1;
       if (n <= p.park_max) have = reserve(reg, n);
       if (have >= 0) {
@@ -778,6 +825,7 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
       }
       after_lcs(r, la, lcs);
     }
+    if constexpr (SPLIT) return;
     if (over) {
       if constexpr (K == 1) {
         text_row = -1;  // the text image's registers are free for the dense steps
@@ -935,9 +983,10 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
     int a = i0, b = i1;
     if (partitioned) {  // slice blockIdx.y of the category's rows, cut at batch boundaries
       const int lo = lsegstart[c], len = lsegstart[c + 1] - lo;
-      const int per = (((len + ny - 1) / ny) + kBatch - 1) / kBatch * kBatch;
-      a = lo + min(len, by * per);
-      b = lo + min(len, (by + 1) * per);
+      const int tot = p.slices_total > 0 ? p.slices_total : ny;
+      const int per = (((len + tot - 1) / tot) + kBatch - 1) / kBatch * kBatch;
+      a = lo + min(len, (by + p.slice_base) * per);
+      b = lo + min(len, (by + p.slice_base + 1) * per);
     }
     const unsigned long long lower = (1ull << c) - 1ull;
     for (int sb = a; sb < b; sb += kBatch * kSub) {
@@ -958,6 +1007,7 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
         }
         if (rows_ok) scan_batch(ib, nrows, okbits, rows_ok, pb * kSub + g);
       }
+      if constexpr (SPLIT) continue;  // no park, no dense pass, no barrier: the finish kernel takes the survivors
       __syncthreads();  // every tile's survivors of this super-batch are parked
       text_row = -1;    // the text image does not outlive the super-batch: its registers are free in the dense pass
       if (threadIdx.x < kSub) {  // the other parity's counters were consumed before the previous super-batch's last barrier
@@ -982,6 +1032,7 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
       pb ^= 1;
     }
   }
+  if constexpr (SPLIT) flush_queue();
 }
 
 }  // namespace nsm
