@@ -369,7 +369,35 @@ def valu_roofline(profile_name, kernel_match, kernel_label, kernel_ms, launches_
         roof["profile"] = f"{pfile.name} missing: run tools/pmc_collect.sh on the GPU box"
         return roof
     prof = json.loads(pfile.read_text())
-    entry = next((v for k, v in prof["kernels"].items() if kernel_match in k), None)
+    if isinstance(kernel_match, tuple):
+        # a grid call that is several launches (the split path of the one-word fuzzy levels grid: scan and finish kernel,
+        # once per round): kernel_match = (kernels..., the kernel launched ONCE per call); the counters of one call are the
+        # kernels' per-launch means times their launches, over the number of calls profiled
+        *names, once = kernel_match
+        per_call = next((v for k, v in prof["kernels"].items() if once in k), None)
+        parts = [v for n in names for k, v in prof["kernels"].items() if n in k]
+        if per_call is None or len(parts) != len(names):
+            roof["profile"] = f"{pfile.name} has no kernels matching {kernel_match!r}"
+            return roof
+        calls = per_call["launches_profiled"]
+        keys = set.intersection(*(set(v["counters"]) for v in parts))
+        counters = {k: sum(v["counters"][k] * v["launches_profiled"] for v in parts) / calls for k in keys}
+        entry = {"counters": counters, "launches_per_call": [v["launches_profiled"] / calls for v in parts],
+                 "mean_us_under_pmc": sum(v["mean_us_under_pmc"] * v["launches_profiled"] for v in parts) / calls}
+        cyc = counters.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+        if cyc > 0 and "SQ_INSTS_VALU" in counters:
+            entry["valu_issue_frac"] = counters["SQ_INSTS_VALU"] * 2 / (1024 * cyc)
+        if cyc > 0 and "SQ_ACTIVE_INST_VALU" in counters:
+            entry["valu_busy_frac"] = counters["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * cyc)
+        if cyc > 0 and "SQ_INSTS_SALU" in counters:
+            entry["salu_issue_frac"] = counters["SQ_INSTS_SALU"] / (256 * cyc)
+        if cyc > 0 and "SQ_LDS_IDX_ACTIVE" in counters:
+            entry["lds_busy_frac"] = counters["SQ_LDS_IDX_ACTIVE"] / (256 * cyc)
+        if all("hbm_bytes_per_launch" in v for v in parts):
+            entry["hbm_bytes_per_launch"] = sum(v["hbm_bytes_per_launch"] * v["launches_profiled"] for v in parts) / calls
+        roof["launches_per_grid_call"] = dict(zip(names, entry["launches_per_call"]))
+    else:
+        entry = next((v for k, v in prof["kernels"].items() if kernel_match in k), None)
     if entry is None:
         roof["profile"] = f"{pfile.name} has no kernel matching {kernel_match!r}"
         return roof
@@ -600,7 +628,9 @@ def run_c5(args, comm, device, steps=None, warmup=None, cpu=True, sub=False):
             "fuzzy_grids_ms_per_step": ms_indel,
             "jaccard_grids_ms_per_step": ms_jac,
         },
-        "roofline": valu_roofline("c5", "indel_levels_park_kernel<1>", "indel_levels_park_kernel<1> (3 launches per step)",
+        "roofline": valu_roofline("c5", ("indel_levels_park_kernel<1, true>", "indel_levels_finish_kernel", "split_begin_kernel"),
+                                  "nsm_indel_levels_grid, split path: indel_levels_park_kernel<1, true> (scan) + "
+                                  "indel_levels_finish_kernel per round (3 grid calls per step)",
                                   ms_indel, len(pairs), local_pairs // len(pairs) * bytes_per_pair, str_bytes // len(pairs),
                                   default_shape=not args.rows and (args.threshold is None or sub) and world == 1),
     }

@@ -336,6 +336,17 @@ static int split_workspace(void* stream, unsigned long long entries, SplitWorksp
 
 }  // namespace nsm
 
+#ifdef NSM_SCAN_STATS
+// variant builds only: copy the one-word scan's work counters to `out[8]` and reset them (synchronises the device)
+extern "C" int nsm_debug_scan_stats(unsigned long long* out) {
+  unsigned long long zero[8] = {0};
+  hipDeviceSynchronize();
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(nsm::g_scan_stats), sizeof(zero));
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(nsm::g_scan_stats), zero, sizeof(zero));
+  return static_cast<int>(e);
+}
+#endif
+
 #ifdef NSM_TILE_STATS
 // variant builds only: copy the tile kernel's work counters to `out[16]` and reset them (synchronises the device)
 extern "C" int nsm_debug_tile_stats(unsigned long long* out) {

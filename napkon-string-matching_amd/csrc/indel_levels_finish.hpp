@@ -14,6 +14,11 @@
 //   symmetric, and 32-bit words suffice unless both strings are longer than 32), and runs Hyyro's recurrence over its own
 //   text.  No wave-uniform operand, no table shared between lanes, hence no grouping of the queue by left row.
 //
+// (Tried: ONE table plane per wave -- 10 KB instead of 20 KB of LDS, 16 waves per CU -- with two sweeps over the text and
+// one carry bit per text position when both strings are longer than 32: configs[4]'s fuzzy grids 289 -> 295 ms; the
+// levels of steps 2 and 3 are mostly longer than 32 code units there, and two table builds cost more than the 64-bit
+// recurrence.)
+//
 // Arithmetic and tests are those of the fused kernel's dense steps (same double operations in the same order; every
 // test that drops a pair is an upper bound), so the hits are identical.
 #pragma once

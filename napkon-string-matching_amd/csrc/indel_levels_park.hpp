@@ -77,9 +77,27 @@ constexpr uint16_t kDeadNeed = 0xffff;
 #define NSM_PARK_H1 0
 #endif
 #ifndef NSM_PARK_OCC
-#define NSM_PARK_OCC __attribute__((amdgpu_waves_per_eu(K == 1 ? 4 : 1, K == 1 ? 4 : 8)))
+#ifndef NSM_SPLIT_WAVES
+#define NSM_SPLIT_WAVES 5  // waves per SIMD of the split path's scan kernel: 4 (115 VGPRs, no scratch) / 5 (96, 72 B of scratch) / 6 -> configs[4] fuzzy grids 311 / 289 / 322 ms
+#endif
+#define NSM_PARK_OCC __attribute__((amdgpu_waves_per_eu(K == 1 ? (SPLIT ? NSM_SPLIT_WAVES : 4) : 1, K == 1 ? (SPLIT ? NSM_SPLIT_WAVES : 4) : 8)))
 #endif
 constexpr int kHeadDwords = 12;  // histogram (4 folded / 8 dwords) | la | row | levels | first row
+
+// Work counters of the scan (variant builds, -DNSM_SCAN_STATS, read by tools/bench_levels.py --scan-stats through
+// nsm_debug_scan_stats): 0 left rows a wave visited, 1 (row, lane) pairs that pass the category predicate, 2 of those
+// alive after the H phase, 3 rows with a live lane (= rows whose step 1 is scored), 4 pairs alive after step 1,
+// 5 two-row passes, 6 one-row passes
+#ifdef NSM_SCAN_STATS
+__device__ unsigned long long g_scan_stats[8];
+#define NSM_SCAN_STAT(slot, v)                                                                     \
+  do {                                                                                             \
+    const unsigned long long stat_v = static_cast<unsigned long long>(v); /* (all lanes evaluate v) */ \
+    if (lane == 0) atomicAdd(&g_scan_stats[slot], stat_v);                                         \
+  } while (0)
+#else
+#define NSM_SCAN_STAT(slot, v) do {} while (0)
+#endif
 
 template <int NB>
 __device__ __forceinline__ uint32_t hist_l1(const uint32_t (&a)[NB], const uint32_t (&b)[NB]) {
@@ -618,6 +636,10 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
       const bool can = ((okbits >> r) & 1u) && nd <= m1;
       need[r * kWave + lane] = can ? static_cast<uint16_t>(nd) : kDeadNeed;
       live |= __any(can) ? (1u << r) : 0u;
+      NSM_SCAN_STAT(0, 1);
+      NSM_SCAN_STAT(1, __popcll(__ballot((okbits >> r) & 1u)));
+      NSM_SCAN_STAT(2, __popcll(__ballot(can)));
+      NSM_SCAN_STAT(3, __any(can) ? 1 : 0);
     }
     if (!live) return;
 #ifdef NSM_X_HONLY
@@ -669,6 +691,7 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
       const unsigned long long who = __ballot(more);
       if (who == 0ull) return;
       const int n = __popcll(who);
+      NSM_SCAN_STAT(4, n);
       if constexpr (SPLIT) {
         if (more)
           qbuf[qn + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(who >> 32),
@@ -753,6 +776,7 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
             }
           }
 #endif
+          NSM_SCAN_STAT(5, 1);
           after_lcs(r, la, 32 - __popc(va));
           after_lcs(r2, la2, 32 - __popc(vb));
           continue;
@@ -773,6 +797,7 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
           continue;
         }
       }
+      NSM_SCAN_STAT(6, 1);
 #ifndef NSM_X_NOPM
       build_pm_staged(r, la);
 #endif

@@ -6,6 +6,7 @@ bit-exact too, the tolerance only documents what BASELINE.json's north_star asks
 import random
 
 import numpy as np
+import torch
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -414,6 +415,65 @@ def test_indel_levels_park_overflow(dev, thr):
         assert coop.as_tuples() == plain.as_tuples()
         _same_hits(coop, want)
         assert len(want) > 5000
+
+
+@pytest.mark.parametrize("extra", [0, 6])  # 6: level strings of 33..64 code units on both sides (the finish kernel's two-sweep LCS)
+@pytest.mark.parametrize("thr", [0.65, 0.7, 0.9])
+def test_indel_levels_split_path(dev, thr, extra, monkeypatch):
+    """One-word level strings at thresholds >= 0.65 take the split path (scan kernel -> global survivor queue -> finish
+    kernel).  It must give the hits of the fused park kernel (NSM_FLAG_PARK), of the wave-wide kernel and of the oracle --
+    also when the queue overflows (NSM_SPLIT_QUEUE_CAP forces it: the hit counter is put back and the gated fused kernel
+    redoes the grid), and when whole right tiles survive step 1 (the wave's LDS buffer is flushed in the middle of a
+    batch)."""
+    from napkon_string_matching_amd import _lib, grid, tables
+    from oracle import native
+
+    rng = random.Random(9091)
+    words = ["".join(rng.choice("abcdefgh") for _ in range(rng.randint(2, 5))) for _ in range(40)]
+
+    def item():
+        n = rng.randint(1, 6)
+        toks = [rng.choice(words) for _ in range(n + 1 + extra)]
+        return [" ".join(sorted(set(toks[: k + 2 + extra])))[:64].strip() for k in range(n)]  # suffix-nested, <= 64 code units
+
+    left = [item() for _ in range(83)]
+    right = [item() for _ in range(64 * 4 + 37)]
+    for k in range(300):  # three hundred near-copies of a few left items: rows whose 64 lanes all stay alive
+        src = list(left[k % 7])
+        if k % 3 == 0 and len(src[-1]) < 60:
+            src[-1] = src[-1] + " zz"
+        right.append(src)
+    assert max(len(s) for it in left + right for s in it) <= 64
+    lcat = np.array([rng.choice([1, 2, 3, 4, 6]) for _ in left], dtype=np.uint64)
+    rcat = np.array([rng.choice([1, 2, 3, 5]) for _ in right], dtype=np.uint64)
+    cps = lambda items: [[[ord(c) for c in s] for s in it] for it in items]
+    for mode, partition in ((_lib.CAT_INTERSECT, True), (_lib.CAT_INTERSECT, False), (_lib.CAT_NONE, False)):
+        li, ls, ri, rs = tables.encode_level_strings(left, right, dev, lcat, rcat, mode, partition=partition)
+        assert ls.stride == 64
+        want = native.levels(True, cps(left), cps(right), thr, lcat, rcat, mode, cap=1 << 17)
+        assert len(want) > 50
+        fused = grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, capacity=1 << 16, park=True)
+        _same_hits(fused, want)
+        for cap in (None, "1", "100", "5000"):
+            if cap is None:
+                monkeypatch.delenv("NSM_SPLIT_QUEUE_CAP", raising=False)
+            else:
+                monkeypatch.setenv("NSM_SPLIT_QUEUE_CAP", cap)
+            split = grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, capacity=1 << 16)
+            assert split.as_tuples() == fused.as_tuples(), (mode, partition, cap)
+            small = grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, capacity=64)  # hit buffer grown once
+            assert small.as_tuples() == fused.as_tuples()
+            # a hit buffer that already holds records: the overflow path puts the counter back to THEIR number
+            buf = grid.HitBuffer(1 << 16, dev)
+            buf.reset()
+            buf.count.fill_(5)
+            lib = _lib.load()
+            cm = li.category_mode if li.category_mode is not None else mode
+            _lib.check(lib.nsm_indel_levels_grid(li.struct(), ls.struct(), ri.struct(), rs.struct(), thr, int(cm), _lib.FLAG_PRUNE,
+                                                 buf.records.data_ptr(), buf.capacity, buf.count.data_ptr(),
+                                                 torch.cuda.current_stream(dev).cuda_stream), "nsm_indel_levels_grid")
+            assert int(buf.count.item()) == 5 + len(want)
+        monkeypatch.delenv("NSM_SPLIT_QUEUE_CAP", raising=False)
 
 
 @pytest.mark.parametrize("hi", [90, 230, 480])

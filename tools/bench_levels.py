@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--threshold", type=float, default=0.7)
     ap.add_argument("--vocab", type=int, default=20_000)
     ap.add_argument("--jaccard-flags", type=int, default=1, help="flags of nsm_jaccard_levels_grid: 1 | 4 (force index) | 8 (no index)")
+    ap.add_argument("--indel-flags", type=int, default=1, help="flags of nsm_indel_levels_grid: 1 | 16 (the fused park kernel)")
+    ap.add_argument("--scan-stats", action="store_true", help="variant build with -DNSM_SCAN_STATS: print the scan's work counters")
     ap.add_argument("--tokens-per-entry", type=int, default=2,
                     help="words per entry; 6 makes the level strings 40..170 code units (multi-word Indel kernels)")
     args = ap.parse_args()
@@ -81,7 +83,7 @@ def main():
         li, ls, ri, rs = str_tables[a, b]
         buf.count.zero_()
         _lib.check(lib.nsm_indel_levels_grid(li.struct(), ls.struct(), ri.struct(), rs.struct(), args.threshold,
-                                             li.category_mode, 1, buf.records.data_ptr(), buf.capacity, buf.count.data_ptr(),
+                                             li.category_mode, args.indel_flags, buf.records.data_ptr(), buf.capacity, buf.count.data_ptr(),
                                              stream), "indel_levels")
         lib.nsm_sort_hits(buf.records.data_ptr(), buf.scratch.data_ptr(), buf.capacity, buf.count.data_ptr(), stream)
 
@@ -102,6 +104,17 @@ def main():
             fn(a, b)
             hits.append(int(buf.count.item()))
         out[label] = {"ms_per_3_grids": dt * 1e3, "pairs_per_s": 3 * args.rows ** 2 / dt, "hits": hits}
+
+    if args.scan_stats:
+        import ctypes
+
+        st = (ctypes.c_ulonglong * 8)()
+        lib.nsm_debug_scan_stats(st)  # reset
+        run_indel(*pairs[0])
+        lib.nsm_debug_scan_stats(st)
+        out["scan_stats_first_grid"] = dict(zip(
+            ["rows_visited", "pairs_in_category", "pairs_alive_after_H", "rows_scored", "pairs_alive_after_step1",
+             "two_row_passes", "one_row_passes"], [int(v) for v in st]))
 
     if args.check:
         from oracle import native
