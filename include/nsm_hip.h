@@ -153,8 +153,10 @@ typedef struct nsm_level_items {
 #define NSM_FLAG_INDEX 4u    /* nsm_jaccard_raw_grid, nsm_jaccard_levels_grid: candidate generation by inverted index (chosen by
                                 itself at low thresholds, where the signature filter stops paying; this forces it) */
 #define NSM_FLAG_NO_INDEX 8u /* the same grids: never use the inverted index (A/B runs, tests) */
-#define NSM_FLAG_PARK 16u /* nsm_indel_levels_grid, strings beyond 64 code units: the round-2 kernel (one right tile per
-                             wavefront, block-shared park) instead of the shared-tile kernel; same hits, A/B runs and tests */
+#define NSM_FLAG_PARK 16u /* nsm_indel_levels_grid: the round-2 kernel alone (one right tile per wavefront, block-shared
+                             park, dense finish inside the kernel) -- instead of the shared-tile kernel for strings beyond 64
+                             code units, and instead of the split path (scan kernel -> survivor queue -> finish kernel) that
+                             strings up to 64 code units take at thresholds >= 0.65; same hits, A/B runs and tests */
 #define NSM_FLAG_WAVE_WIDE 2u /* nsm_indel_levels_grid: score every step wave-wide (no block-cooperative
                                  parking of the surviving pairs); same hits, kept for A/B runs and tests */
 
@@ -178,7 +180,12 @@ int nsm_indel_raw_grid(const nsm_str_table* left, const nsm_str_table* right, do
                        uint32_t flags, nsm_hit* hits, uint64_t capacity,
                        unsigned long long* hit_count, void* stream);
 
-/* Levels-mode Indel ratio over per-level strings. */
+/* Levels-mode Indel ratio over per-level strings.
+ * Device workspace: for strings up to 64 code units at thresholds >= 0.65 (with NSM_FLAG_PRUNE and histograms) the library
+ * keeps a survivor queue per (device, stream) -- allocated with hipMalloc at the first such call, grown when a larger grid
+ * needs it (that call synchronises the stream), at most 1 GB, never freed; the call itself stays asynchronous.  Hits are
+ * appended behind the records already counted in hit_count, as everywhere.  NSM_SPLIT_QUEUE_CAP (environment, entries)
+ * bounds the queue: the tests use it to force the overflow path. */
 int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_table* left_strings,
                           const nsm_level_items* right, const nsm_str_table* right_strings,
                           double threshold, int32_t category_mode, uint32_t flags, nsm_hit* hits,

@@ -27,6 +27,12 @@
 //         reference's order with the histogram bound after each; hits are emitted from here.
 //
 // Every test that drops a pair is an upper bound (exact: hits are identical to the wave-wide kernel's).
+//
+// SPLIT = true (round 3, one-word strings at thresholds where few pairs outlive step 1): the same stage / H / scan, but the
+// survivors of step 1 go to a GLOBAL queue (collected per wave in LDS, one atomic per ~200 entries) and a second kernel
+// finishes them lane-per-pair (indel_levels_finish.hpp).  No park, no dense pass, no block barrier, and without the dense
+// pass's registers the scan fits 96 VGPRs: 5 waves per SIMD and no scratch traffic to speak of, where the fused kernel
+// (4 waves, 256 B of scratch per lane) moved 234 GB per launch.  configs[4], three fuzzy grids: 409 -> 289 ms.
 #pragma once
 
 namespace nsm {
