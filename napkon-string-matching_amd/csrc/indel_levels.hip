@@ -298,10 +298,19 @@ namespace nsm {
 
 // Device workspace of the split path (survivor queue + control words), one per (device, stream), grown on demand and kept:
 // a grid call must not allocate per launch, and calls on different streams may overlap.
+// The finish kernel of round k runs on a stream of the library's own, beside the scan of round k + 1 (two queue halves):
+// the scan leaves ~40 % of the VALU issue slots and nearly all of the HBM bandwidth unused, the finish kernel waits on
+// gathers.  Events order the two streams; the caller's stream waits for the last finish before the call's last launches,
+// so the call behaves like any other sequence of launches on `stream`.
+#ifndef NSM_SPLIT_OVERLAP
+#define NSM_SPLIT_OVERLAP 1
+#endif
 struct SplitWorkspace {
-  unsigned long long* queue = nullptr;
+  unsigned long long* queue = nullptr;  // two halves of `cap` entries
   unsigned long long* ctl = nullptr;  // [0] hit counter at the start | [1] overflow flag (int) | [2 ..] queue counter per round
   unsigned long long cap = 0;
+  hipStream_t side = nullptr;
+  hipEvent_t scanned[2] = {nullptr, nullptr}, finished[2] = {nullptr, nullptr};
 };
 constexpr int kSplitMaxRounds = 62;
 constexpr int kSplitCtlWords = 2 + kSplitMaxRounds;
@@ -317,6 +326,16 @@ static int split_workspace(void* stream, unsigned long long entries, SplitWorksp
   if (!w.ctl) {
     e = hipMalloc(reinterpret_cast<void**>(&w.ctl), kSplitCtlWords * 8);
     if (e != hipSuccess) return hip_status(e, "hipMalloc(split control words)");
+    if (NSM_SPLIT_OVERLAP) {
+      int lo = 0, hi = 0;
+      e = hipDeviceGetStreamPriorityRange(&lo, &hi);  // (hi = the numerically lowest = greatest priority)
+      if (e == hipSuccess) e = hipStreamCreateWithPriority(&w.side, hipStreamNonBlocking, hi);
+      for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+        e = hipEventCreateWithFlags(&w.scanned[k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&w.finished[k], hipEventDisableTiming);
+      }
+      if (e != hipSuccess) return hip_status(e, "split path: side stream / events");
+    }
   }
   if (w.cap < entries) {
     if (w.queue) {  // (launches that still read the old queue are ahead of this call in the same stream)
@@ -326,7 +345,7 @@ static int split_workspace(void* stream, unsigned long long entries, SplitWorksp
       w.cap = 0;
       if (e != hipSuccess) return hip_status(e, "hipFree(survivor queue)");
     }
-    e = hipMalloc(reinterpret_cast<void**>(&w.queue), entries * 8);
+    e = hipMalloc(reinterpret_cast<void**>(&w.queue), entries * 8 * (NSM_SPLIT_OVERLAP ? 2 : 1));
     if (e != hipSuccess) return hip_status(e, "hipMalloc(survivor queue)");
     w.cap = entries;
   }
@@ -645,7 +664,8 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
       fp.qcap = entries;
       const long long per_round = (slices_all + rounds - 1) / rounds;
       int* qflag = reinterpret_cast<int*>(ws.ctl + 1);
-      for (long long rd = 0; rd * per_round < slices_all; ++rd) {
+      long long n_rounds = 0;
+      for (long long rd = 0; rd * per_round < slices_all; ++rd, ++n_rounds) {
         const long long s0 = rd * per_round;
         const long long ns = slices_all - s0 < per_round ? slices_all - s0 : per_round;
         sq.slice_base = static_cast<int>(s0);
@@ -657,16 +677,41 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
         } else {
           sgrid.y = static_cast<unsigned>(ns);
         }
+        const int half = ws.side ? static_cast<int>(rd & 1) : 0;
+        unsigned long long* qhalf = ws.queue + static_cast<size_t>(half) * ws.cap;
+        hipStream_t fs = hs;
+        if (ws.side) {
+          fs = ws.side;
+          if (rd >= 2) {  // the finish kernel of round rd - 2 has read this half
+            const hipError_t e = hipStreamWaitEvent(hs, ws.finished[half], 0);
+            if (e != hipSuccess) return hip_status(e, "hipStreamWaitEvent(finished)");
+          }
+        }
         hipLaunchKernelGGL((indel_levels_park_kernel<1, true>), sgrid, dim3(pw * kWave), scan_lds, hs, left->first,
                            left->nlev, left->orig, left->cat, left->seg_start, left_strings->codes, left_strings->len,
                            left_strings->hist, right->first, right->nlev, right->orig, right->cat, right->seg,
                            right_strings->codes, right_strings->len, right_strings->hist, hits, hit_count, sq,
-                           right->seg_start, ws.queue, ws.ctl + 2 + rd, qflag, static_cast<const int*>(nullptr));
+                           right->seg_start, qhalf, ws.ctl + 2 + rd, qflag, static_cast<const int*>(nullptr));
+        if (ws.side) {
+          hipError_t e = hipEventRecord(ws.scanned[half], hs);
+          if (e == hipSuccess) e = hipStreamWaitEvent(fs, ws.scanned[half], 0);
+          if (e != hipSuccess) return hip_status(e, "split path: scan -> finish ordering");
+        }
         hipLaunchKernelGGL(indel_levels_finish_kernel, dim3(kFinishBlocks), dim3(kWave),
-                           static_cast<size_t>(fp.pm_stride) * 2 * kWave * 4, hs, left->first, left->nlev, left->orig,
+                           static_cast<size_t>(fp.pm_stride) * 2 * kWave * 4, fs, left->first, left->nlev, left->orig,
                            left_strings->codes, left_strings->len, left_strings->hist, right->first, right->nlev,
                            right->orig, right_strings->codes, right_strings->len, right_strings->hist, hits, hit_count,
-                           ws.queue, ws.ctl + 2 + rd, qflag, fp);
+                           qhalf, ws.ctl + 2 + rd, qflag, fp);
+        if (ws.side) {
+          const hipError_t e = hipEventRecord(ws.finished[half], fs);
+          if (e != hipSuccess) return hip_status(e, "hipEventRecord(finished)");
+        }
+      }
+      if (ws.side) {  // join: the last (two) finish kernels before the counter is looked at
+        for (int k = 0; k < 2 && k < n_rounds; ++k) {
+          const hipError_t e = hipStreamWaitEvent(hs, ws.finished[k], 0);
+          if (e != hipSuccess) return hip_status(e, "hipStreamWaitEvent(join)");
+        }
       }
       hipLaunchKernelGGL(split_end_kernel, dim3(1), dim3(kWave), 0, hs, ws.ctl, hit_count);
       gate = qflag;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Re-measure everything kept under profiles/ on the GPU box (run through gpurun from the repo root):
-#   tools/refresh_profiles.sh <stamp> [part...]        parts: bench trace pmc (default: all)   -> gpurun_out/final/*
+#   tools/refresh_profiles.sh <stamp> [part...]        parts: pmc bench trace (default: all, in this order)   -> gpurun_out/final/*
 # <stamp> = `git describe --always --dirty` of the tree that was sent (the box has no .git).
 #   bench  the JSON lines of bench.py (c2 c3 c4 c5 term) and of the levels / RAW-terms tool benches
 #   trace  rocprofv3 --kernel-trace --stats of the default bench.py run, of c5 and of term
@@ -8,7 +8,7 @@
 set -e -o pipefail
 export TMPDIR=/tmp
 stamp=${1:-unknown}; shift || true
-parts=${@:-bench trace pmc}
+parts=${@:-pmc bench trace}  # pmc first: its pmc_<w>.json are copied into profiles/ of this tree, so that the bench lines that follow carry a roofline that matches the sources
 out=gpurun_out/final
 mkdir -p $out
 for part in $parts; do
@@ -32,6 +32,7 @@ for part in $parts; do
     ;;
   pmc)
     tools/pmc_collect.sh $out $stamp c2 c2low c3 c4 c5 term levels
+    cp $out/pmc_*.json profiles/
     ;;
   esac
 done
