@@ -613,7 +613,7 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
       // partitioned: y = slices of every category's row range (all blocks have work); ~256 rows per slice when
       // the rows spread over ~32 categories, enough blocks to fill the chip when they do not
 #ifndef NSM_PARK_SLICE_ROWS
-#define NSM_PARK_SLICE_ROWS 8192
+#define NSM_PARK_SLICE_ROWS 16384  // (configs[4], split path: 4096 / 8192 / 16384 / 32768 rows -> fuzzy grids 294 / 283 / 279 / 282 ms)
 #endif
       long long slices = (left->n + NSM_PARK_SLICE_ROWS - 1) / NSM_PARK_SLICE_ROWS;
       if (slices < 1) slices = 1;
