@@ -7,6 +7,7 @@ on/off and a threshold, and requires the hit list (score, i, j) to be IDENTICAL 
 non-zero with the failing round's seed.  Test infrastructure: not part of the product path.
 """
 import argparse
+import os
 import json
 import random
 import sys
@@ -80,7 +81,7 @@ def main():
             print(json.dumps({"progress": counts, "round_seed": rnd}), flush=True)
             next_report += 60.0
         rng = random.Random(rnd)
-        family = rng.choice(["jaccard_raw", "indel_raw", "jaccard_levels", "indel_levels", "indel_levels", "wide"])
+        family = rng.choice(["jaccard_raw", "indel_raw", "jaccard_levels", "indel_levels", "indel_levels", "indel_split", "wide"])
         counts[family] = counts.get(family, 0) + 1
         thr = rng.choice(thresholds)
         n, m = rng.randint(1, 400), rng.randint(1, 600)
@@ -193,6 +194,13 @@ def main():
                 n, m = min(n, 120), min(m, 200)
                 lcat, rcat = lcat[:n], rcat[:m]
                 hi = rng.choice([10, 40, 64, 64, 120, 250, 500])
+                queue_cap = None
+                if family == "indel_split":
+                    # one-word strings at thresholds where the split path runs (scan -> survivor queue -> finish kernel),
+                    # sometimes with a queue so small that it overflows (gated fused fallback)
+                    hi = rng.choice([12, 30, 40, 64])
+                    thr = rng.choice([0.65, 0.7, 0.75, 0.8, 0.9, 1.0])
+                    queue_cap = rng.choice([None, None, "1", "64", "2000"])
                 alphabet = rng.choice(["abc ", "abcdefghij klm", "abcdefghijklmnopqrstuvwxyz0123456789 "])
                 max_levels = rng.choice([1, 2, 4, 4, 7])
                 item = lambda: [rand_string(rng, alphabet, 0, hi) for _ in range(rng.randint(1, max_levels))]
@@ -209,11 +217,17 @@ def main():
                 cps = lambda items: [[[ord(c) for c in s] for s in it] for it in items]
                 want = native.levels(True, cps(left), cps(right), thr, lcat, rcat, mode, cap=1 << 18)
                 # multi-word strings: the shared-tile kernel (default) or the round-2 park kernel
-                park = ls.stride > 64 and rng.random() < 0.25
-                prune = rng.random() < 0.8
+                # (one-word strings: the split path at thresholds >= 0.65, else -- and with park -- the fused park kernel)
+                park = rng.random() < 0.25 and family != "indel_split"
+                prune = rng.random() < 0.8 or family == "indel_split"
+                if queue_cap is None:
+                    os.environ.pop("NSM_SPLIT_QUEUE_CAP", None)
+                else:
+                    os.environ["NSM_SPLIT_QUEUE_CAP"] = queue_cap
                 check(grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, park=park, prune=prune), want,
-                      f"indel_levels hi={hi} |alphabet|={len(alphabet)} levels<={max_levels} thr={thr} mode={mode} "
-                      f"partition={partition} ncat={ncat} park={park} prune={prune} stride={ls.stride} {n}x{m}")
+                      f"{family} hi={hi} |alphabet|={len(alphabet)} levels<={max_levels} thr={thr} mode={mode} "
+                      f"partition={partition} ncat={ncat} park={park} prune={prune} stride={ls.stride} queue_cap={queue_cap} {n}x{m}")
+                os.environ.pop("NSM_SPLIT_QUEUE_CAP", None)
     print(json.dumps({"ok": True, "rounds": counts, "oracle_hits_compared": total_hits, "seconds": args.seconds,
                       "first_seed": args.seed + 1, "last_seed": rnd}))
 
