@@ -631,7 +631,7 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
       }
     }
     const int* gate = nullptr;
-    if (split) {
+    if (split && pw == 4) {  // (the scan kernel's LDS layout is compiled for four waves; always the case at pm_stride <= 64)
       // rounds: the expected number of survivors (2 % of the pairs visited; a partition visits ~1/16 of the grid or less)
       // against the queue
       double expect = static_cast<double>(left->n) * static_cast<double>(right->n) * 0.02 * (left->seg ? 1.0 / 16 : 1.0);
@@ -654,7 +654,7 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
       sq.fin_rows = 1;
       sq.qcap = entries;  // (not ws.cap: a smaller grid after a larger one keeps its own bound, results do not depend on history)
       sq.slices_total = static_cast<int>(slices_all);
-      const size_t scan_lds = pw * (tbl_bytes + fixed_wave + kQueueBuf * 8) + 66 * 16 + 8 + 4 * sub * 4;
+      const size_t scan_lds = pw * (2 * kSplitTableBytes + fixed_wave + kQueueBuf * 8) + 66 * 16 + 8 + 4 * sub * 4;
       FinishParams fp;
       fp.pm_stride = q.pm_stride;
       fp.pad_code = left_strings->alphabet;

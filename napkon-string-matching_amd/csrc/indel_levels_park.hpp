@@ -57,6 +57,15 @@ struct ParkParams {
 
 // Survivor queue of the split path (SPLIT = true: scan kernel here, finish kernel in indel_levels_finish.hpp): one 64-bit
 // entry per pair that is still alive after step 1 and has steps to go:  left row << 31 | right row << 7 | step-1 LCS.
+// (SPLIT) FOUR left rows per pass: two mask tables at a fixed distance, so that one address register serves both
+// (ds_read_b64 with an immediate offset) -- one address op and two reads per code unit for four rows, four independent chains
+#ifndef NSM_SPLIT_QUAD
+#define NSM_SPLIT_QUAD 0
+#endif
+#ifndef NSM_SPLIT_TABLE_BYTES
+#define NSM_SPLIT_TABLE_BYTES 512
+#endif
+constexpr int kSplitTableBytes = NSM_SPLIT_TABLE_BYTES;  // 64 entries of 8 bytes (the split path requires pm_stride <= 64)
 constexpr int kQueueBuf = 256;  // entries a wave collects in LDS before it reserves room in the global queue
 constexpr int kQueueRowBits = 24;
 __host__ __device__ constexpr unsigned long long queue_entry(int i, int j, int lcs) {
@@ -176,17 +185,20 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
 #endif
   constexpr bool kStageEarly = NSM_STAGE_EARLY != 0;
   constexpr bool kPrefetchRows = false;
-  const int waves = blockDim.x >> 6;
+  // (SPLIT: four waves per block and the histogram bound are the launcher's conditions for the split path; as constants they
+  // turn the wave's LDS layout into immediates -- 72 -> 48 B of scratch, configs[4]'s fuzzy grids 279 -> 264 ms)
+  const int waves = SPLIT ? 4 : static_cast<int>(blockDim.x >> 6);
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
 
   const int tbl_entries = p.pm_stride * kPmWords<K>;
-  const size_t wave_bytes = static_cast<size_t>(p.fin_rows) * tbl_entries * 8 + (K > 1 ? 16 * K * kWave * 4 : 0) +
+  const size_t tables_bytes = SPLIT ? 2 * kSplitTableBytes : static_cast<size_t>(p.fin_rows) * tbl_entries * 8;
+  const size_t wave_bytes = tables_bytes + (K > 1 ? 16 * K * kWave * 4 : 0) +
                             kBatch * kWave * 2 + (K > 1 ? kBatch * kWave * 8 : 0) + kBatch * 3 * kHeadDwords * 4 + kBatch * kRow +
                             (SPLIT ? kQueueBuf * 8 : 0);
   unsigned char* wbase = reinterpret_cast<unsigned char*>(s_mem) + wave * wave_bytes;
   unsigned long long* pm = reinterpret_cast<unsigned long long*>(wbase);
-  uint32_t* wtext = reinterpret_cast<uint32_t*>(pm + static_cast<size_t>(p.fin_rows) * tbl_entries);
+  uint32_t* wtext = reinterpret_cast<uint32_t*>(pm + tables_bytes / 8);
   uint16_t* need = reinterpret_cast<uint16_t*>(wtext + (K > 1 ? 16 * K * kWave : 0));
   double* sc = reinterpret_cast<double*>(need + kBatch * kWave);  // (K > 1) running scores of the rows that go on wave-wide
   uint32_t* head = reinterpret_cast<uint32_t*>(sc + (K > 1 ? kBatch * kWave : 0));
@@ -247,7 +259,7 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
   // kernel's time at configs[4]'s shape).
   const int i0 = partitioned ? 0 : (by + p.slice_base) * p.rows_per_chunk;
   const int i1 = partitioned ? p.n_left : min(p.n_left, i0 + p.rows_per_chunk);
-  const bool use_hist = p.use_hist != 0;
+  const bool use_hist = SPLIT ? true : p.use_hist != 0;
 
   if (threadIdx.x == 0) s_cats = 0ull;
   if (threadIdx.x < 2 * kSub) {
@@ -735,9 +747,68 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
         // per code unit instead of 5, half the LDS reads, half the table builds and loop overhead.)
         const int r2 = rows ? __builtin_ctz(rows) : -1;
         const int la2 = r2 >= 0 ? wave_first(static_cast<int>(head[r2 * 3 * kHeadDwords + NB])) : 64;
+        if constexpr (SPLIT && NSM_SPLIT_QUAD) {
+          if (la <= 32 && la2 <= 32 && __builtin_popcount(rows) >= 3) {
+            const uint32_t rest = rows & (rows - 1);
+            const int r3 = __builtin_ctz(rest), r4 = __builtin_ctz(rest & (rest - 1));
+            const int la3 = wave_first(static_cast<int>(head[r3 * 3 * kHeadDwords + NB]));
+            const int la4 = wave_first(static_cast<int>(head[r4 * 3 * kHeadDwords + NB]));
+            if (la3 <= 32 && la4 <= 32) {
+              rows = rest & (rest - 1);
+              rows &= rows - 1;
+              if (lane < tbl_entries) {
+                pm[lane] = 0ull;
+                pm[kSplitTableBytes / 8 + lane] = 0ull;
+              }
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              uint32_t* pm32 = reinterpret_cast<uint32_t*>(pm);
+              if (lane < la) atomicOr(&pm32[2 * lstr[r * kRow + lane]], 1u << lane);
+              if (lane < la2) atomicOr(&pm32[2 * lstr[r2 * kRow + lane] + 1], 1u << lane);
+              if (lane < la3) atomicOr(&pm32[kSplitTableBytes / 4 + 2 * lstr[r3 * kRow + lane]], 1u << lane);
+              if (lane < la4) atomicOr(&pm32[kSplitTableBytes / 4 + 2 * lstr[r4 * kRow + lane] + 1], 1u << lane);
+              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              asm volatile("" : "+v"(lowmask), "+v"(sh16));
+              uint32_t va = ~0u, vb = ~0u, vc = ~0u, vd = ~0u;
+#pragma unroll
+              for (int g = 0; g < 8; ++g) {
+                if (g * 8 < nchars) {
+                  unsigned long long m[8], n[8];
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) {
+                    // (volatile: left alone hipcc fuses the two reads into ds_read2st64_b64, which the LDS serves at a
+                    // quarter of the rate of two ds_read_b64 -- indel_tile_lcs.hpp)
+                    using lds_u64 = const volatile __attribute__((address_space(3))) unsigned long long;
+                    const uint32_t a0 = taddr[4 * g + q] & lowmask, a1 = taddr[4 * g + q] >> sh16;
+                    m[2 * q] = reinterpret_cast<lds_u64*>(a0)[0];
+                    n[2 * q] = reinterpret_cast<lds_u64*>(a0)[kSplitTableBytes / 8];
+                    m[2 * q + 1] = reinterpret_cast<lds_u64*>(a1)[0];
+                    n[2 * q + 1] = reinterpret_cast<lds_u64*>(a1)[kSplitTableBytes / 8];
+                  }
+#pragma unroll
+                  for (int q = 0; q < 8; ++q) {
+                    va = lcs_step32(va, static_cast<uint32_t>(m[q]));
+                    vb = lcs_step32(vb, static_cast<uint32_t>(m[q] >> 32));
+                    vc = lcs_step32(vc, static_cast<uint32_t>(n[q]));
+                    vd = lcs_step32(vd, static_cast<uint32_t>(n[q] >> 32));
+                  }
+                }
+              }
+              NSM_SCAN_STAT(5, 2);
+              after_lcs(r, la, 32 - __popc(va));
+              after_lcs(r2, la2, 32 - __popc(vb));
+              after_lcs(r3, la3, 32 - __popc(vc));
+              after_lcs(r4, la4, 32 - __popc(vd));
+              continue;
+            }
+          }
+        }
         if (la <= 32 && la2 <= 32) {
           rows &= rows - 1;
-          for (int c = lane; c < tbl_entries; c += kWave) pm[c] = 0ull;
+          if constexpr (SPLIT) pm[lane] = 0ull;  // (the table region holds 64 entries: no bound to test)
+          else
+            for (int c = lane; c < tbl_entries; c += kWave) pm[c] = 0ull;
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           uint32_t* pm32 = reinterpret_cast<uint32_t*>(pm);
