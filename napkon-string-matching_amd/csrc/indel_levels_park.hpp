@@ -291,6 +291,7 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
   const int jorig = rorig[jc];
   const uint64_t catr = (p.cat_mode != NSM_CAT_NONE) ? rcat[jc] : 0ull;
   const int lr_max = wave_max_i32(valid ? lr : 0);
+  const unsigned long long lr_deep_m = __builtin_amdgcn_ballot_w64(lr > 1);  // (SPLIT) lanes whose item has more than one level
   // level strings of steps 1..3: lengths and histograms stay in registers for the H phase
   int lb_t[3];
   uint32_t hb[3][NB];
@@ -339,6 +340,14 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
       return -1;
     }
     return have;
+  };
+
+  // "some lane": the ballot builtin on the bool (SPLIT only: the fused kernel's code is left as measured).  (Spelling the
+  // per-row selects of the H phase and of the category predicate as integer arithmetic, to get rid of the v_cndmask + v_cmp
+  // pairs hipcc builds around them, changed nothing: 251.3 vs 250.7 ms.)
+  auto any_lane = [](bool pred) -> bool {
+    if constexpr (SPLIT) return __builtin_amdgcn_ballot_w64(pred) != 0ull;
+    else return __any(pred) != 0;
   };
 
   // (SPLIT) the wave's collected survivors go to the global queue: one atomic per ~200 entries.  A full queue raises the
@@ -620,6 +629,9 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
 
     // ---- H: need[r][lane]
     uint32_t live = 0;
+    // (SPLIT) the rows' step-1 lengths and depths as bytes of two scalars: the row loop and after_lcs read them with scalar
+    // shifts instead of an LDS round trip + v_readfirstlane per row
+    unsigned long long la_pack = 0ull, ll_pack = 0ull;
     for (uint32_t rows = rows_ok; rows;) {
       const int r = __builtin_ctz(rows);
       rows &= rows - 1;
@@ -653,7 +665,11 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
       const int m1 = (n1 - static_cast<int>(l1[0])) >> 1;  // LCS of step 1 <= m1 (<= min(la, lb))
       const bool can = ((okbits >> r) & 1u) && nd <= m1;
       need[r * kWave + lane] = can ? static_cast<uint16_t>(nd) : kDeadNeed;
-      live |= __any(can) ? (1u << r) : 0u;
+      live |= any_lane(can) ? (1u << r) : 0u;
+      if constexpr (SPLIT) {
+        la_pack |= static_cast<unsigned long long>(wave_first(la[0]) & 0xff) << (8 * r);
+        ll_pack |= static_cast<unsigned long long>(ll & 0xff) << (8 * r);
+      }
       NSM_SCAN_STAT(0, 1);
       NSM_SCAN_STAT(1, __popcll(__ballot((okbits >> r) & 1u)));
       NSM_SCAN_STAT(2, __popcll(__ballot(can)));
@@ -695,13 +711,35 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
     uint32_t over = 0;  // rows whose survivors were too many to park: their remaining steps follow below
     // what follows a row's step-1 LCS: the survivors are parked, or the row is marked for the dense steps below
     auto after_lcs = [&](int r, int la, int lcs) __attribute__((always_inline)) {
-      const int ll = wave_first(static_cast<int>(head[r * 3 * kHeadDwords + NB + 2]));
+      const int ll = SPLIT ? static_cast<int>((ll_pack >> (8 * r)) & 0xff)
+                           : wave_first(static_cast<int>(head[r * 3 * kHeadDwords + NB + 2]));
       const int S = max(ll, lr);
       const int nd = need[r * kWave + lane];
+      if constexpr (SPLIT) {
+        // (masks combined as scalars)
+        const bool alive = lcs >= nd;  // (kDeadNeed > any LCS)
+        const unsigned long long alive_m = __builtin_amdgcn_ballot_w64(alive);
+        if (alive_m == 0ull) return;
+        const unsigned long long deep_m = ll > 1 ? ~0ull : lr_deep_m;  // lanes whose pair has more than one step
+        if (alive_m & ~deep_m) {  // single-step pairs (both items have one level): final here
+          const double score = ratio_of(la, lb, lcs) * 0.5;
+          const bool hit = alive && S <= 1 && score >= p.threshold;
+          emit_hits_wave(hits, p.cap, count, hit, score, lorig[ib + r], jorig);
+        }
+        const unsigned long long who = alive_m & deep_m;
+        if (who == 0ull) return;
+        NSM_SCAN_STAT(4, __popcll(who));
+        if (alive && S > 1)
+          qbuf[qn + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(who >> 32),
+                                              __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(who), 0u))] = queue_entry(ib + r, jc, lcs);
+        qn += __popcll(who);
+        if (qn > kQueueBuf - kWave) flush_queue();
+        return;
+      }
       const bool alive = nd != kDeadNeed && lcs >= nd;  // can still reach the threshold
-      if (!__any(alive)) return;
+      if (!any_lane(alive)) return;
       const bool more = alive && S > 1;
-      if (__any(alive && !more)) {  // single-step pairs (both items have one level): final here
+      if (any_lane(alive && !more)) {  // single-step pairs (both items have one level): final here
         const double score = ratio_of(la, lb, lcs) * 0.5;
         const bool hit = alive && !more && score >= p.threshold;
         emit_hits_wave(hits, p.cap, count, hit, score, lorig[ib + r], jorig);
@@ -710,14 +748,6 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
       if (who == 0ull) return;
       const int n = __popcll(who);
       NSM_SCAN_STAT(4, n);
-      if constexpr (SPLIT) {
-        if (more)
-          qbuf[qn + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(who >> 32),
-                                              __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(who), 0u))] = queue_entry(ib + r, jc, lcs);
-        qn += n;
-        if (qn > kQueueBuf - kWave) flush_queue();
-        return;
-      }
       int have = -1;
       if (n <= p.park_max) have = reserve(reg, n);
       if (have >= 0) {
@@ -739,14 +769,17 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
     for (uint32_t rows = live; rows;) {
       const int r = __builtin_ctz(rows);
       rows &= rows - 1;
-      const int la = wave_first(static_cast<int>(head[r * 3 * kHeadDwords + NB]));
+      const int la = SPLIT ? static_cast<int>((la_pack >> (8 * r)) & 0xff)
+                           : wave_first(static_cast<int>(head[r * 3 * kHeadDwords + NB]));
       if constexpr (K == 1) {
         // Two left rows per pass when both fit 32-bit words: row A's masks in the low, row B's in the high half
         // of ONE table entry, so a code unit of the text costs one address op and one ds_read_b64 for both
         // rows, and the two recurrences are independent chains the SIMD can interleave.  (Per row: 4.5 VALU ops
         // per code unit instead of 5, half the LDS reads, half the table builds and loop overhead.)
         const int r2 = rows ? __builtin_ctz(rows) : -1;
-        const int la2 = r2 >= 0 ? wave_first(static_cast<int>(head[r2 * 3 * kHeadDwords + NB])) : 64;
+        const int la2 = r2 < 0 ? 64
+                        : SPLIT ? static_cast<int>((la_pack >> (8 * r2)) & 0xff)
+                                : wave_first(static_cast<int>(head[r2 * 3 * kHeadDwords + NB]));
         if constexpr (SPLIT && NSM_SPLIT_QUAD) {
           if (la <= 32 && la2 <= 32 && __builtin_popcount(rows) >= 3) {
             const uint32_t rest = rows & (rows - 1);
@@ -1105,7 +1138,7 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
           if (partitioned) ok = ok && myseg == c && ((cl & catr & lower) == 0ull);
           else if (p.cat_mode != NSM_CAT_NONE) ok = ok && category_match(cl, catr, p.cat_mode);
           okbits |= ok ? (1u << r) : 0u;
-          rows_ok |= __any(ok) ? (1u << r) : 0u;
+          rows_ok |= any_lane(ok) ? (1u << r) : 0u;
         }
         if (rows_ok) scan_batch(ib, nrows, okbits, rows_ok, pb * kSub + g);
       }
