@@ -682,6 +682,16 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
 
     // ---- step 1, wave-wide
     if (!(K == 1 && kStageEarly)) stage_strings(ib, live, 1);
+    // (SPLIT) the code unit at position `lane` of every row's staged string, fetched once per batch (eight reads in flight
+    // together): per pass the read -> address -> ds_or chain was an LDS round trip per row before the LCS could start
+    unsigned long long my_codes = 0ull;
+    if constexpr (SPLIT && K == 1) {
+      uint32_t c8[kBatch];
+#pragma unroll
+      for (int q = 0; q < kBatch; ++q) c8[q] = lstr[q * kRow + lane];
+#pragma unroll
+      for (int q = 0; q < kBatch; ++q) my_codes |= static_cast<unsigned long long>(c8[q]) << (8 * q);
+    }
     const int rrow = rrow0 + max(0, min(1, lr - 1));
     if constexpr (K == 1) {
       if (rrow != text_row) {  // step 1 reads the same right level for every batch
@@ -710,11 +720,11 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
     const int nchars = wave_max_i32(valid ? lb : 0);
     uint32_t over = 0;  // rows whose survivors were too many to park: their remaining steps follow below
     // what follows a row's step-1 LCS: the survivors are parked, or the row is marked for the dense steps below
-    auto after_lcs = [&](int r, int la, int lcs) __attribute__((always_inline)) {
+    auto after_lcs = [&](int r, int la, int lcs, int nd_early = -1) __attribute__((always_inline)) {
       const int ll = SPLIT ? static_cast<int>((ll_pack >> (8 * r)) & 0xff)
                            : wave_first(static_cast<int>(head[r * 3 * kHeadDwords + NB + 2]));
       const int S = max(ll, lr);
-      const int nd = need[r * kWave + lane];
+      const int nd = nd_early >= 0 ? nd_early : need[r * kWave + lane];
       if constexpr (SPLIT) {
         // (masks combined as scalars)
         const bool alive = lcs >= nd;  // (kDeadNeed > any LCS)
@@ -845,8 +855,24 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           uint32_t* pm32 = reinterpret_cast<uint32_t*>(pm);
-          if (lane < la) atomicOr(&pm32[2 * lstr[r * kRow + lane]], 1u << lane);
-          if (lane < la2) atomicOr(&pm32[2 * lstr[r2 * kRow + lane] + 1], 1u << lane);
+          int nd_a = -1, nd_b = -1;
+          if constexpr (SPLIT) {
+            // codes from the batch's prefetch; the rows' `need` is requested here too, so that it has arrived when the LCS
+            // ends.  (The ORs stay under `lane < la`: unconditional, with a zero bit for the lanes past the string's end, they
+            // all hit the pad symbol's entry -- 30-odd same-address atomics per pass, 254 -> 303 ms.)
+            if (lane < la) atomicOr(&pm32[2 * static_cast<uint32_t>((my_codes >> (8 * r)) & 0xffu)], 1u << lane);
+            if (lane < la2) atomicOr(&pm32[2 * static_cast<uint32_t>((my_codes >> (8 * r2)) & 0xffu) + 1], 1u << lane);
+#ifndef NSM_SPLIT_ND_EARLY
+#define NSM_SPLIT_ND_EARLY 1
+#endif
+            if (NSM_SPLIT_ND_EARLY) {
+              nd_a = need[r * kWave + lane];
+              nd_b = need[r2 * kWave + lane];
+            }
+          } else {
+            if (lane < la) atomicOr(&pm32[2 * lstr[r * kRow + lane]], 1u << lane);
+            if (lane < la2) atomicOr(&pm32[2 * lstr[r2 * kRow + lane] + 1], 1u << lane);
+          }
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
           __builtin_amdgcn_wave_barrier();
           asm volatile("" : "+v"(lowmask), "+v"(sh16));
@@ -887,8 +913,8 @@ __global__ __launch_bounds__(kBlock) NSM_PARK_OCC void indel_levels_park_kernel(
           }
 #endif
           NSM_SCAN_STAT(5, 1);
-          after_lcs(r, la, 32 - __popc(va));
-          after_lcs(r2, la2, 32 - __popc(vb));
+          after_lcs(r, la, 32 - __popc(va), nd_a);
+          after_lcs(r2, la2, 32 - __popc(vb), nd_b);
           continue;
         }
       }
