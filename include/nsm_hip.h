@@ -183,7 +183,9 @@ int nsm_indel_raw_grid(const nsm_str_table* left, const nsm_str_table* right, do
 /* Levels-mode Indel ratio over per-level strings.
  * Device workspace: for strings up to 64 code units at thresholds >= 0.65 (with NSM_FLAG_PRUNE and histograms) the library
  * keeps a survivor queue per (device, stream) -- allocated with hipMalloc at the first such call, grown when a larger grid
- * needs it (that call synchronises the stream), at most 1 GB, never freed; the call itself stays asynchronous.  Hits are
+ * needs it (that call synchronises the stream), at most 2 x 1 GB, never freed; the call itself stays asynchronous, and a
+ * call on a stream that is being captured into a graph never allocates (it uses the stream's queue if an eager call has
+ * sized it, the single-kernel path otherwise).  Hits are
  * appended behind the records already counted in hit_count, as everywhere.  NSM_SPLIT_QUEUE_CAP (environment, entries)
  * bounds the queue: the tests use it to force the overflow path. */
 int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_table* left_strings,

@@ -315,13 +315,20 @@ struct SplitWorkspace {
 constexpr int kSplitMaxRounds = 62;
 constexpr int kSplitCtlWords = 2 + kSplitMaxRounds;
 
-static int split_workspace(void* stream, unsigned long long entries, SplitWorkspace* out) {
+// `capturing`: the stream records a hipGraph -- nothing may be allocated or synchronised now; *out stays empty (queue ==
+// nullptr) unless the stream's workspace exists and is large enough, and the caller takes the single-kernel path instead.
+static int split_workspace(void* stream, unsigned long long entries, bool capturing, SplitWorkspace* out) {
   static std::mutex mu;
   static std::map<std::pair<int, void*>, SplitWorkspace> all;
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return hip_status(e, "hipGetDevice");
   std::lock_guard<std::mutex> lock(mu);
+  if (capturing) {
+    auto it = all.find(std::make_pair(dev, stream));
+    if (it != all.end() && it->second.ctl && it->second.cap >= entries) *out = it->second;
+    return 0;
+  }
   SplitWorkspace& w = all[std::make_pair(dev, stream)];
   if (!w.ctl) {
     e = hipMalloc(reinterpret_cast<void**>(&w.ctl), kSplitCtlWords * 8);
@@ -645,9 +652,12 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
       unsigned long long entries = static_cast<unsigned long long>(expect / static_cast<double>(rounds)) + (1ull << 16);
       if (entries > qmax) entries = qmax;
       SplitWorkspace ws;
-      const int rc = split_workspace(stream, entries, &ws);
-      if (rc != 0) return rc;
       hipStream_t hs = static_cast<hipStream_t>(stream);
+      hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(hs, &capture) != hipSuccess) capture = hipStreamCaptureStatusNone;
+      const int rc = split_workspace(stream, entries, capture != hipStreamCaptureStatusNone, &ws);
+      if (rc != 0) return rc;
+      if (ws.queue != nullptr) {
       hipLaunchKernelGGL(split_begin_kernel, dim3(1), dim3(kWave), 0, hs, ws.ctl, kSplitCtlWords, hit_count);
       ParkParams sq = q;
       sq.park_slots = 0;
@@ -715,6 +725,7 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
       }
       hipLaunchKernelGGL(split_end_kernel, dim3(1), dim3(kWave), 0, hs, ws.ctl, hit_count);
       gate = qflag;
+      }  // (else: a capturing stream without a sized workspace -- the fused kernel below does the whole grid, ungated)
     }
     unsigned long long* no_queue = nullptr;
     int* no_flag = nullptr;

@@ -476,6 +476,58 @@ def test_indel_levels_split_path(dev, thr, extra, monkeypatch):
         monkeypatch.delenv("NSM_SPLIT_QUEUE_CAP", raising=False)
 
 
+def test_indel_levels_split_path_under_graph_capture(dev):
+    """The split path keeps a device workspace per (device, stream) and runs its finish kernels on a stream of its own.
+    Captured into a hipGraph it must neither allocate nor lose work: on a stream whose workspace an eager call has sized
+    the capture records the split path (fork / join through the library's events), on a stream that never ran it the call
+    falls back to the single-kernel path; both replays give the eager call's hits."""
+    from napkon_string_matching_amd import _lib, grid, tables
+
+    rng = random.Random(515)
+    words = ["".join(rng.choice("abcdefgh") for _ in range(rng.randint(2, 5))) for _ in range(40)]
+
+    def item():
+        n = rng.randint(1, 5)
+        toks = [rng.choice(words) for _ in range(n + 1)]
+        return [" ".join(sorted(set(toks[: k + 2]))) for k in range(n)]
+
+    left = [item() for _ in range(150)]
+    right = [item() for _ in range(700)] + [list(left[k % 9]) for k in range(200)]
+    li, ls, ri, rs = tables.encode_level_strings(left, right, dev, None, None, _lib.CAT_NONE)
+    assert ls.stride == 64
+    want = grid.indel_levels_grid(li, ls, ri, rs, 0.7, park=True).as_tuples()
+    assert len(want) > 100
+    lib = _lib.load()
+
+    def launch(buf, stream):
+        buf.count.zero_()
+        _lib.check(lib.nsm_indel_levels_grid(li.struct(), ls.struct(), ri.struct(), rs.struct(), 0.7, _lib.CAT_NONE, _lib.FLAG_PRUNE,
+                                             buf.records.data_ptr(), buf.capacity, buf.count.data_ptr(), stream.cuda_stream),
+                   "nsm_indel_levels_grid")
+
+    def hits_of(buf):
+        n = int(buf.count.item())
+        rec = grid.sort_hits_device(buf, n)
+        return rec.as_tuples()
+
+    for warm in (True, False):
+        stream = torch.cuda.Stream(dev)
+        buf = grid.HitBuffer(1 << 14, dev)
+        buf.reset()
+        with torch.cuda.stream(stream):
+            if warm:
+                launch(buf, stream)  # sizes this stream's workspace
+                stream.synchronize()
+                assert hits_of(buf) == want
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream):
+                launch(buf, stream)
+            for _ in range(2):
+                g.replay()
+                torch.cuda.synchronize(dev)
+                assert hits_of(buf) == want, warm
+
+
 @pytest.mark.parametrize("hi", [90, 230, 480])
 def test_indel_levels_long_strings(dev, hi):
     from napkon_string_matching_amd import _lib, grid, tables
