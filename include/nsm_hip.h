@@ -156,7 +156,7 @@ typedef struct nsm_level_items {
 #define NSM_FLAG_PARK 16u /* nsm_indel_levels_grid: the round-2 kernel alone (one right tile per wavefront, block-shared
                              park, dense finish inside the kernel) -- instead of the shared-tile kernel for strings beyond 64
                              code units, and instead of the split path (scan kernel -> survivor queue -> finish kernel) that
-                             strings up to 64 code units take at thresholds >= 0.65; same hits, A/B runs and tests */
+                             strings up to 64 code units take at thresholds >= 0.7; same hits, A/B runs and tests */
 #define NSM_FLAG_WAVE_WIDE 2u /* nsm_indel_levels_grid: score every step wave-wide (no block-cooperative
                                  parking of the surviving pairs); same hits, kept for A/B runs and tests */
 
@@ -181,7 +181,7 @@ int nsm_indel_raw_grid(const nsm_str_table* left, const nsm_str_table* right, do
                        unsigned long long* hit_count, void* stream);
 
 /* Levels-mode Indel ratio over per-level strings.
- * Device workspace: for strings up to 64 code units at thresholds >= 0.65 (with NSM_FLAG_PRUNE and histograms) the library
+ * Device workspace: for strings up to 64 code units at thresholds >= 0.7 (with NSM_FLAG_PRUNE and histograms) the library
  * keeps a survivor queue per (device, stream) -- allocated with hipMalloc at the first such call, grown when a larger grid
  * needs it (that call synchronises the stream), at most 2 x 1 GB, never freed; the call itself stays asynchronous, and a
  * call on a stream that is being captured into a graph never allocates (it uses the stream's queue if an eager call has

@@ -589,7 +589,10 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
     // overflows anyway (the survival rate is a guess) raises a flag: the hit counter is put back and the fused kernel,
     // launched behind the rounds and gated on that flag, redoes the grid.  NSM_FLAG_PARK = the fused kernel alone.
 #ifndef NSM_SPLIT_MIN_THRESHOLD
-#define NSM_SPLIT_MIN_THRESHOLD 0.65
+// (3 x 100k^2 C5-shaped grids, split vs fused, ms: 0.65 112.9 vs 81.9, 0.675 43.1 vs 32.5, 0.7 11.9 vs 18.1, 0.8 11.7 vs 14.3,
+// 0.9 5.4 vs 7.4 -- below 0.7 the survivors multiply (5x the hits per 0.025) and lane-per-pair finishing costs more than the
+// dense passes it replaces)
+#define NSM_SPLIT_MIN_THRESHOLD 0.7
 #endif
 #ifndef NSM_SPLIT_QUEUE_MAX
 #define NSM_SPLIT_QUEUE_MAX (128ull << 20)  // entries (1 GB)

@@ -418,9 +418,9 @@ def test_indel_levels_park_overflow(dev, thr):
 
 
 @pytest.mark.parametrize("extra", [0, 6])  # 6: level strings of 33..64 code units on both sides (the finish kernel's two-sweep LCS)
-@pytest.mark.parametrize("thr", [0.65, 0.7, 0.9])
+@pytest.mark.parametrize("thr", [0.7, 0.8, 0.9])
 def test_indel_levels_split_path(dev, thr, extra, monkeypatch):
-    """One-word level strings at thresholds >= 0.65 take the split path (scan kernel -> global survivor queue -> finish
+    """One-word level strings at thresholds >= 0.7 take the split path (scan kernel -> global survivor queue -> finish
     kernel).  It must give the hits of the fused park kernel (NSM_FLAG_PARK), of the wave-wide kernel and of the oracle --
     also when the queue overflows (NSM_SPLIT_QUEUE_CAP forces it: the hit counter is put back and the gated fused kernel
     redoes the grid), and when whole right tiles survive step 1 (the wave's LDS buffer is flushed in the middle of a

@@ -199,7 +199,7 @@ def main():
                     # one-word strings at thresholds where the split path runs (scan -> survivor queue -> finish kernel),
                     # sometimes with a queue so small that it overflows (gated fused fallback)
                     hi = rng.choice([12, 30, 40, 64])
-                    thr = rng.choice([0.65, 0.7, 0.75, 0.8, 0.9, 1.0])
+                    thr = rng.choice([0.7, 0.7, 0.75, 0.8, 0.9, 1.0])
                     queue_cap = rng.choice([None, None, "1", "64", "2000"])
                 alphabet = rng.choice(["abc ", "abcdefghij klm", "abcdefghijklmnopqrstuvwxyz0123456789 "])
                 max_levels = rng.choice([1, 2, 4, 4, 7])
@@ -217,7 +217,7 @@ def main():
                 cps = lambda items: [[[ord(c) for c in s] for s in it] for it in items]
                 want = native.levels(True, cps(left), cps(right), thr, lcat, rcat, mode, cap=1 << 18)
                 # multi-word strings: the shared-tile kernel (default) or the round-2 park kernel
-                # (one-word strings: the split path at thresholds >= 0.65, else -- and with park -- the fused park kernel)
+                # (one-word strings: the split path at thresholds >= 0.7, else -- and with park -- the fused park kernel)
                 park = rng.random() < 0.25 and family != "indel_split"
                 prune = rng.random() < 0.8 or family == "indel_split"
                 if queue_cap is None:
