@@ -1,6 +1,11 @@
 #!/bin/bash
 # same-box experiments on the one-word fuzzy levels split path (scan -> queue -> finish) against the fused park kernel:
 #   tools/ab_split.sh        -> gpurun_out/split/ab.txt
+# needs these variant builds (made here, they travel to the GPU box with the tree):
+#   tools/build_variant.sh scanstats indel_levels.hip "-DNSM_SCAN_STATS"
+#   tools/build_variant.sh thr0      indel_levels.hip "-DNSM_SPLIT_MIN_THRESHOLD=0.0"
+#   tools/build_variant.sh w5        indel_levels.hip "-DNSM_SPLIT_WAVES=5"      (the default now; 4 / 6 for the comparison)
+# results of the round's runs: profiles/r03_split_ab.txt
 V=napkon-string-matching_amd/csrc/variants
 out=gpurun_out/split; mkdir -p $out
 show='import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print("%-44s fuzzy %8.2f ms / 3 grids  hits %s %s" % (sys.argv[1], d["fuzzy_match"]["ms_per_3_grids"], d["fuzzy_match"]["hits"], json.dumps(d.get("scan_stats_first_grid", ""))))'
