@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: pair-comparisons/sec of the all-pairs match loop on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload all|c2|c2low|c3|c4|c5|term] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload all|c2|c2low|c3|c4|c5|c5w|term] [--no-cpu-baseline]
 
 N > 1 is launched by the driver as
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -11,12 +11,15 @@ on the GPU (threshold test included), order the hits canonically and -- for N > 
 the (score, i, j) hits of every rank.  Left rows are block-sharded over the ranks, the right side is
 replicated; per-GPU work is fixed as N grows ("weak").
 
-Workload at N = 1 is BASELINE.json configs[1] ("c2": 50k x 50k token-id sets, mean 8 ids,
-intersection_vs_union, threshold 0.5); `--workload c3` runs configs[2] (200k x 200k strings,
-fuzzy_match, threshold 0.8).  `--workload c4` is configs[3] (1M x 1M token-id sets, threshold 0.8, the
-1M left rows divided over the ranks: "strong"); `--workload c5` is configs[4] (three 500k-item
-cohorts, 4 levels, 32 categories, filter_categories, both score functions back to back through the
-levels-mode kernels, left rows of every cohort pair divided over the ranks: "strong").
+The headline workload is BASELINE.json configs[2] ("c3": 200k x 200k strings of 16..64 code units, fuzzy_match,
+threshold 0.8) -- the LARGEST configuration BASELINE.json quotes on one GPU (4e10 pairs per step; configs[1], "c2":
+50k x 50k token-id sets, mean 8 ids, intersection_vs_union, threshold 0.5, is 2.5e9).  `--workload c4` is configs[3]
+(1M x 1M token-id sets, threshold 0.8, the 1M left rows divided over the ranks: "strong"); `--workload c5` is
+configs[4] (three 500k-item cohorts, 4 levels, 32 categories, filter_categories, both score functions back to back
+through the levels-mode kernels, left rows of every cohort pair divided over the ranks: "strong") at config.yml's
+score threshold 0.7; `--workload c5w` is the same shape on WORD-LIKE text (20 000 distinct words of 3..7 letters
+instead of "t<digits>") at the threshold the reference's flow hands to the grid when a cache threshold is set, 0.5
+(types/comparable_data.py:102-108, config.yml:11-12), with the 0.7 run reported beside it.
 
 The JSON line carries, besides the driver's contract fields:
   roofline      dominant kernel against the bound it can actually approach, the VALU issue rate (this path
@@ -34,12 +37,16 @@ The JSON line carries, besides the driver's contract fields:
                 compulsory byte counts, and the profile's stamp (git head, hash of csrc/ -- a stale profile shows).
   exhaustive    the same grid with the exact prune disabled (every pair's full comparison evaluated)
   cpu_baseline  the oracle's restatement of the reference's loop, 1 core, bounded sample
-  c2low c3 c4 c5 term   (default `--workload all`) every other BASELINE config and the reference's default
-                configuration, timed in the SAME invocation after the headline, each under the same contract
-                (W warm-up steps, K timed steps between fences; c5: min(K, 5) steps of six 500k x 500k grids) with
-                its own value / ms_per_step / steps / kernel_ms / roofline / exhaustive / cpu_baseline.  N = 1 runs
-                all five; N > 1 runs the two configs BASELINE.json quotes on 8 GPUs (c4, c5: left rows divided
-                over the ranks, "strong").  `--workload <one>` times that workload alone.
+  c2 c2low c4 c5 c5w term   (default `--workload all`) every other BASELINE config, configs[4] on word-like text
+                and the reference's default configuration, timed in the SAME invocation after the headline, each
+                under the same contract (W warm-up steps, K timed steps between fences; c5 / c5w: min(K, 5) / min(K, 3)
+                steps of six 500k x 500k grids) with its own value / ms_per_step / steps / kernel_ms / roofline /
+                exhaustive / cpu_baseline.  N = 1 runs all six; N > 1 runs the configs BASELINE.json quotes on 8
+                GPUs (c4, c5 and c5w: left rows divided over the ranks, "strong").  `--workload <one>` times that
+                workload alone.
+  config.sub    the sub-records' numbers once more, as plain scalars under the `config` object (a parser that keeps
+                `config` and drops unknown top-level keys still carries them): per workload ms_per_step, value,
+                kernel_ms, roofline_frac, exhaustive_ms_per_step, cpu_baseline_value, steps.
 """
 import argparse
 import hashlib
@@ -69,23 +76,28 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=("all", "c2", "c2low", "c3", "c4", "c5", "term"), default="all",
-                    help="all = the c2 headline line with every other workload attached as a sub-record")
+    ap.add_argument("--workload", choices=("all", "c2", "c2low", "c3", "c4", "c5", "c5w", "term"), default="all",
+                    help="all = the c3 headline line with every other workload attached as a sub-record")
     ap.add_argument("--rows", type=int, default=0, help="override rows per side per GPU (debug)")
     ap.add_argument("--right-rows", type=int, default=0, help="override the right side's rows (debug)")
     ap.add_argument("--threshold", type=float, default=None, help="override the workload's threshold (debug)")
     ap.add_argument("--id-range", type=int, default=0, help="c2 / c4: draw token ids from [0, N) instead of 2^17 (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the exhaustive (prune off) run and c5w's second run at the score threshold (profiling passes)")
     ap.add_argument("--graph", type=int, default=0, help="1: replay each step as one captured hipGraph")
     ap.add_argument("--serial-sort", action="store_true",
                     help="N = 1: order the hits on the launch stream instead of a second stream (no overlap with the next step's grid)")
     ap.add_argument("--capacity", type=int, default=1 << 13)
+    ap.add_argument("--split-workspace-mb", type=int, default=-1,
+                    help="c5 / c5w: MiB of split-path workspace handed to nsm_indel_levels_grid (-1 = what the library asks "
+                         "for, 0 = none: the single-kernel path; A/B runs)")
     ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
                     help="gloo = CPU-staged rehearsal of the N > 1 path (e.g. 2 ranks sharing one GPU)")
     ap.add_argument("--allow-gloo", action="store_true",
                     help="if RCCL cannot be brought up on every rank, run the exchange staged through host memory "
                          "instead of exiting non-zero (the JSON's config.exchange says which one ran)")
-    ap.add_argument("--no-c4", action="store_true", help="(kept for old command lines) same as --workload c2")
+    ap.add_argument("--no-c4", action="store_true", help="(kept for old command lines) the headline alone, no sub-records")
     return ap.parse_args()
 
 
@@ -221,7 +233,7 @@ class Workload:
             flags = self.flag_prune if prune else _lib.FLAG_WAVE_WIDE
             _lib.check(
                 self.lib.nsm_indel_levels_grid(st[0], st[1], st[2], st[3], float(self.threshold), _lib.CAT_NONE, flags,
-                                               buf.records.data_ptr(), buf.capacity, buf.count.data_ptr(), stream),
+                                               buf.records.data_ptr(), buf.capacity, buf.count.data_ptr(), 0, 0, stream),
                 self.kernel,
             )
             return
@@ -472,10 +484,11 @@ def cpu_baseline(work, budget_pairs):
     }
 
 
-def run_c5(args, comm, device, steps=None, warmup=None, cpu=True, sub=False):
+def run_c5(args, comm, device, steps=None, warmup=None, cpu=True, sub=False, words=False):
     """BASELINE configs[4]: three hap / pop / suep shaped cohorts, levels mode (compare_terms), categories
     filtered, intersection_vs_union then fuzzy_match for every cohort pair.  One step = the six grids.
-    The left rows of every cohort pair are divided over the ranks (total work fixed: "strong")."""
+    The left rows of every cohort pair are divided over the ranks (total work fixed: "strong").
+    ``words`` = the "c5w" workload: the same shape over 20 000 distinct word-like tokens, at the CACHE threshold 0.5."""
     import numpy as np
     import torch
 
@@ -485,13 +498,22 @@ def run_c5(args, comm, device, steps=None, warmup=None, cpu=True, sub=False):
     warmup = max(1, args.warmup if warmup is None else warmup)
     lib = _lib.load()
     rows = args.rows or 500_000
-    # max(cache 0.5, score 0.7), config.yml:11-12; as a sub-record of the default run a --threshold meant for c2 is ignored
-    threshold = 0.7 if (args.threshold is None or sub) else args.threshold
+    # Thresholds (config.yml:11-12: cache_threshold 0.5, score_threshold 0.7).  The reference's compare() hands gen_comparable
+    # the CACHE threshold when one is set (types/comparable_data.py:102-108), so a Matcher run on config.yml scores the
+    # grid at 0.5 and filters to 0.7 afterwards.  c5's "t<digits>" level strings share a 12-symbol alphabet: unrelated
+    # items score ~0.6 and a 500k x 500k grid at 0.5 would report ~1e10 hits -- an artefact of the digit corpus, so c5 is
+    # quoted at the SCORE threshold 0.7 and says so; c5w (word-like text, where unrelated items score ~0.35) runs at 0.5,
+    # with its 0.7 run beside it.  As a sub-record of the default run a --threshold meant for the headline is ignored.
+    name = "c5w" if words else "c5"
+    default_threshold = 0.5 if words else 0.7
+    threshold = default_threshold if (args.threshold is None or sub) else args.threshold
     mode = _lib.CAT_INTERSECT_OR_BOTH_EMPTY
     names = ("hap", "pop", "suep")
+    lex = synthetic.word_vocabulary(20_000) if words else None
     cohorts = {}
     for k, nm in enumerate(names):  # the same on every rank (seeded); pop / suep carry 1 % near-duplicates of hap
-        cohorts[nm] = synthetic.c5_cohort(rows, 11 + k, plant_from=cohorts.get("hap"))
+        cohorts[nm] = synthetic.c5_cohort(rows, 11 + k, plant_from=cohorts.get("hap"), lex=lex)
+    alphabet = synthetic.c5_alphabet(cohorts["hap"])
     pairs = [("hap", "pop"), ("hap", "suep"), ("pop", "suep")]
     lo, hi = distributed.shard_bounds(rows, rank, world)
     # fuzzy_match operands (join_sorted + default_process of every level), as dense code units: generated
@@ -511,94 +533,139 @@ def run_c5(args, comm, device, steps=None, warmup=None, cpu=True, sub=False):
         codes_a, len_a, first_a, nlev_a = level_codes[a]
         e = ca["entries"]
         left_levels = (codes_a[lo * e: hi * e], len_a[lo * e: hi * e], first_a[lo:hi] - lo * e, nlev_a[lo:hi])
-        li, ls, ri, rs = tables.encode_level_codes(left_levels, level_codes[b], len(synthetic.C5_ALPHABET), device,
+        li, ls, ri, rs = tables.encode_level_codes(left_levels, level_codes[b], len(alphabet), device,
                                                    ca["cat"][lo:hi], cb["cat"], mode, left_offset=lo)
         grids.append(("jaccard", (lt, rt), (lt.struct(), rt.struct()), lt.category_mode))
         grids.append(("indel", (li, ls, ri, rs), (li.struct(), ls.struct(), ri.struct(), rs.struct()), li.category_mode))
     torch.cuda.synchronize(device)
     t_encode = time.perf_counter() - t0
 
-    capacity = max(args.capacity, 1 << 16)
-    bufs = [grid.HitBuffer(capacity, device) for _ in range(2)]
-    for b in bufs:
-        b.scratch = torch.empty_like(b.records)
-    gathered = [torch.empty((world,) + tuple(b.storage.shape), dtype=b.storage.dtype, device=device) for b in bufs]
-    pending = [None, None]
     stream = torch.cuda.current_stream(device).cuda_stream
-    turn = [0]
-    counts = []
-    jaccard_flags = _lib.FLAG_PRUNE | (_lib.FLAG_INDEX if threshold > 0 else 0)
+    jaccard_flags = _lib.FLAG_PRUNE | _lib.FLAG_INDEX
+    state = {"threshold": float(threshold), "ws": None}
+
+    def size_workspace():
+        # the split path's survivor queue is the CALLER's (ABI 4): one torch tensor, sized to the largest fuzzy grid and
+        # shared by the three (they run one after the other on the launch stream)
+        want = max(int(lib.nsm_indel_levels_workspace_bytes(g[2][0], g[2][1], g[2][2], g[2][3], state["threshold"], 1))
+                   for g in grids if g[0] == "indel")
+        if args.split_workspace_mb >= 0 and want > 0:
+            want = args.split_workspace_mb << 20
+        state["ws"] = grid.split_workspace(want, device) if want > 0 else None
 
     def launch(g, b):
         kind, _keep, st, cat_mode = g
+        thr = state["threshold"]
         if kind == "jaccard":
             # (the product's host path forces the inverted-index kernel when the vocabulary has >= 8192 tokens --
             # types/comparable_data.py:_levels_grid; the synthetic cohorts draw from 20 000 words)
-            rc = lib.nsm_jaccard_levels_grid(st[0], st[1], float(threshold), cat_mode, jaccard_flags, b.records.data_ptr(),
+            rc = lib.nsm_jaccard_levels_grid(st[0], st[1], thr, cat_mode, jaccard_flags, b.records.data_ptr(),
                                              b.capacity, b.count.data_ptr(), stream)
         else:
-            rc = lib.nsm_indel_levels_grid(st[0], st[1], st[2], st[3], float(threshold), cat_mode, 1, b.records.data_ptr(),
-                                           b.capacity, b.count.data_ptr(), stream)
+            ws = state["ws"]
+            rc = lib.nsm_indel_levels_grid(st[0], st[1], st[2], st[3], thr, cat_mode, 1, b.records.data_ptr(),
+                                           b.capacity, b.count.data_ptr(), ws.data_ptr() if ws is not None else 0,
+                                           ws.numel() * 8 if ws is not None else 0, stream)
         _lib.check(rc, kind + "_levels_grid")
 
-    def step(record=False):
+    # hit buffers sized from a counting pass (the counter keeps counting past the capacity: include/nsm_hip.h)
+    def probe_capacity():
+        b = grid.HitBuffer(1, device)
+        most = 0
         for g in grids:
-            k = turn[0] & 1
-            turn[0] += 1
-            b = bufs[k]
-            if pending[k] is not None:
-                pending[k].wait()
-                pending[k] = None
             b.count.zero_()
             launch(g, b)
-            _lib.check(lib.nsm_sort_hits(b.records.data_ptr(), b.scratch.data_ptr(), b.capacity, b.count.data_ptr(), stream),
-                       "nsm_sort_hits")
-            if world > 1:
-                pending[k] = comm.gather_hits(b, gathered[k], async_op=True)
-            if record:
-                counts.append(int(b.count.item()))
+            most = max(most, int(b.count.item()))
+        cap = max(args.capacity, 1 << 16)
+        while cap < most + most // 8:
+            cap <<= 1
+        return cap
 
-    def fence():
-        for k in (0, 1):
-            if pending[k] is not None:
-                pending[k].wait()
-                pending[k] = None
-        comm.barrier()
-        torch.cuda.synchronize(device)
+    def measure(n_steps, n_warmup):
+        size_workspace()
+        capacity = probe_capacity()
+        bufs = [grid.HitBuffer(capacity, device) for _ in range(2)]
+        for b in bufs:
+            b.scratch = torch.empty_like(b.records)
+        gathered = [torch.empty((world,) + tuple(b.storage.shape), dtype=b.storage.dtype, device=device) for b in bufs]
+        pending = [None, None]
+        turn = [0]
+        counts = []
 
-    for _ in range(warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    fence()
-    dt = comm.max_seconds(time.perf_counter() - t0)
-    step(record=True)
-    fence()
-    if max(counts) > capacity:
-        raise SystemExit(f"hit buffer overflow ({max(counts)} > {capacity}); raise --capacity")
-
-    # dominant kernel: the three fuzzy grids of a step, HIP events on the launch stream
-    def kernel_ms(kind, reps):
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        b = bufs[0]
-        torch.cuda.synchronize(device)
-        ev0.record()
-        for _ in range(reps):
+        def step(record=False):
             for g in grids:
-                if g[0] == kind:
-                    launch(g, b)
-        ev1.record()
-        torch.cuda.synchronize(device)
-        return ev0.elapsed_time(ev1) / reps
+                k = turn[0] & 1
+                turn[0] += 1
+                b = bufs[k]
+                if pending[k] is not None:
+                    pending[k].wait()
+                    pending[k] = None
+                b.count.zero_()
+                launch(g, b)
+                _lib.check(lib.nsm_sort_hits(b.records.data_ptr(), b.scratch.data_ptr(), b.capacity, b.count.data_ptr(), 0, rows,
+                                             stream), "nsm_sort_hits")
+                if world > 1:
+                    pending[k] = comm.gather_hits(b, gathered[k], async_op=True)
+                if record:
+                    counts.append(int(b.count.item()))
 
-    reps = max(2, min(steps, 5))
-    ms_indel, ms_jac = kernel_ms("indel", reps), kernel_ms("jaccard", reps)
+        def fence():
+            for k in (0, 1):
+                if pending[k] is not None:
+                    pending[k].wait()
+                    pending[k] = None
+            comm.barrier()
+            torch.cuda.synchronize(device)
+
+        for _ in range(n_warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step()
+        fence()
+        dt = comm.max_seconds(time.perf_counter() - t0)
+        step(record=True)
+        fence()
+        if max(counts) > capacity:
+            raise SystemExit(f"hit buffer overflow ({max(counts)} > {capacity}); raise --capacity")
+
+        # dominant kernel: the three fuzzy grids of a step, HIP events on the launch stream
+        def kernel_ms(kind, reps):
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            b = bufs[0]
+            torch.cuda.synchronize(device)
+            ev0.record()
+            for _ in range(reps):
+                for g in grids:
+                    if g[0] == kind:
+                        launch(g, b)
+            ev1.record()
+            torch.cuda.synchronize(device)
+            return ev0.elapsed_time(ev1) / reps
+
+        reps = max(2, min(n_steps, 5))
+        out = {"dt": dt, "counts": counts, "ms_indel": kernel_ms("indel", reps), "ms_jac": kernel_ms("jaccard", reps),
+               "capacity": capacity, "overflow_word": int(state["ws"][1].item()) & 0xFFFFFFFF if state["ws"] is not None else None}
+        del bufs, gathered
+        return out
+
+    m = measure(steps, warmup)
+    dt, counts, ms_indel, ms_jac = m["dt"], m["counts"], m["ms_indel"], m["ms_jac"]
+    split_used = state["ws"] is not None
     pairs_per_step = 2 * len(pairs) * rows * rows  # both score functions over every cohort pair
     local_pairs = len(pairs) * (hi - lo) * rows    # pairs one fuzzy pass of this rank scores
     bytes_per_pair = 2 * 4 * 64                     # both items' level storage: 4 level strings of 64 B each
     str_bytes = sum(t.nbytes() for g in grids if g[0] == "indel" for t in (g[1][1], g[1][3]))
+    if split_used:
+        kernel_match = ("indel_levels_park_kernel<1, true>", "indel_levels_finish_kernel", "split_begin_kernel")
+        kernel_label = ("nsm_indel_levels_grid, split path: indel_levels_park_kernel<1, true> (scan) + "
+                        "indel_levels_finish_kernel per round (3 grid calls per step)")
+    else:
+        kernel_match = "indel_levels_park_kernel<1, false>"
+        kernel_label = "nsm_indel_levels_grid, single-kernel path: indel_levels_park_kernel<1> (3 grid calls per step)"
+    text = ("20 000 distinct word-like tokens of 3..7 letters (level strings mean 30 / max 63 code units)" if words
+            else '"t<digits>" tokens of 20 000 (12-symbol alphabet)')
     result = {
         "metric": "pair-comparisons/sec (whole node), N x M all-pairs",
         "value": pairs_per_step * steps / dt,
@@ -613,13 +680,18 @@ def run_c5(args, comm, device, steps=None, warmup=None, cpu=True, sub=False):
         "dtype": "int32 (intersection_vs_union) + u64 (fuzzy_match), f64 scores",
         "data": "synthetic",
         "config": {
-            "workload": f"C5: 3 cohorts x {rows} items (4 levels, ~8 tokens, 1-2 of 32 categories), compare_terms levels mode, "
-                        f"filter_categories, intersection_vs_union then fuzzy_match, threshold {threshold}",
+            "workload": f"{name.upper()}: 3 cohorts x {rows} items (4 levels, ~8 tokens, 1-2 of 32 categories; {text}), "
+                        f"compare_terms levels mode, filter_categories, intersection_vs_union then fuzzy_match, threshold {threshold}",
             "mode": "MATCHER",
             "threshold": threshold,
+            "threshold_note": ("the cache threshold: what the reference's compare() passes to gen_comparable when one is set "
+                               "(types/comparable_data.py:102-108, config.yml:11)" if threshold == 0.5 else
+                               "config.yml:12's score threshold; the reference's compare() would hand the grid the cache "
+                               "threshold 0.5 -- see c5w for that regime on word-like text" if threshold == 0.7 else "override"),
             "pairs_per_step": pairs_per_step,
             "hits_per_grid_this_rank": counts,
             "hits_per_grid_all_ranks": [comm.sum_int(c) for c in counts],
+            "hit_capacity": m["capacity"],
             "sharding": f"left rows of every cohort pair block-sharded over {world} rank(s), right replicated, hits all-gathered",
             "exchange": comm.exchange,
             "rccl_ranks_seen": comm.rccl_ranks,
@@ -627,13 +699,26 @@ def run_c5(args, comm, device, steps=None, warmup=None, cpu=True, sub=False):
             "level_string_generation_seconds_once": round(t_generate, 2),
             "fuzzy_grids_ms_per_step": ms_indel,
             "jaccard_grids_ms_per_step": ms_jac,
+            "fuzzy_path": "split (scan -> survivor queue in a caller-owned workspace -> finish)" if split_used else "single kernel",
+            "split_workspace_bytes": int(state["ws"].numel() * 8) if split_used else 0,
+            "split_queue_overflowed": bool(m["overflow_word"]) if split_used else None,
         },
-        "roofline": valu_roofline("c5", ("indel_levels_park_kernel<1, true>", "indel_levels_finish_kernel", "split_begin_kernel"),
-                                  "nsm_indel_levels_grid, split path: indel_levels_park_kernel<1, true> (scan) + "
-                                  "indel_levels_finish_kernel per round (3 grid calls per step)",
+        "roofline": valu_roofline(name, kernel_match, kernel_label,
                                   ms_indel, len(pairs), local_pairs // len(pairs) * bytes_per_pair, str_bytes // len(pairs),
                                   default_shape=not args.rows and (args.threshold is None or sub) and world == 1),
     }
+    if words and threshold == default_threshold and not args.no_extras:
+        # ... and the same grids at config.yml's score threshold (what the result keeps after the cache filter)
+        state["threshold"] = 0.7
+        m7 = measure(max(1, min(steps, 2)), 1)
+        result["at_score_threshold"] = {
+            "threshold": 0.7, "steps": max(1, min(steps, 2)), "ms_per_step": m7["dt"] / max(1, min(steps, 2)) * 1e3,
+            "fuzzy_grids_ms_per_step": m7["ms_indel"], "jaccard_grids_ms_per_step": m7["ms_jac"],
+            "hits_per_grid_this_rank": m7["counts"],
+            "fuzzy_path": "split" if state["ws"] is not None else "single kernel",
+            "split_queue_overflowed": bool(m7["overflow_word"]) if state["ws"] is not None else None,
+        }
+        state["threshold"] = float(threshold)
     if rank == 0 and world == 1 and cpu and not args.no_cpu_baseline:
         from oracle import compare as oc
         from oracle import score_functions as osf
@@ -690,6 +775,7 @@ def run_raw(args, comm, device, name, rows=0, right_rows=0, threshold=None, step
     stream = torch.cuda.current_stream(device).cuda_stream
     lib = work.lib
     step_no = [0]
+    id_limit = max(comm.sum_int(work.n), work.m)  # every reported row id is below it (nsm_sort_hits: fewer key bits)
 
     # The three dependent launches of a step (zero the counter, grid kernel, hit ordering) are captured
     # once per hit buffer and mode into a hipGraph and replayed: one submission per step.
@@ -704,7 +790,7 @@ def run_raw(args, comm, device, name, rows=0, right_rows=0, threshold=None, step
                 s = torch.cuda.current_stream(device).cuda_stream
                 b.count.zero_()
                 work.launch(b, s, prune)
-                lib.nsm_sort_hits(b.records.data_ptr(), b.scratch.data_ptr(), b.capacity, b.count.data_ptr(), s)
+                lib.nsm_sort_hits(b.records.data_ptr(), b.scratch.data_ptr(), b.capacity, b.count.data_ptr(), 0, id_limit, s)
             graphs[key] = g
         return graphs[key]
 
@@ -733,15 +819,15 @@ def run_raw(args, comm, device, name, rows=0, right_rows=0, threshold=None, step
             work.launch(b, stream, prune)
             grid_done[k].record(main)
             side.wait_event(grid_done[k])
-            _lib.check(lib.nsm_sort_hits(b.records.data_ptr(), b.scratch.data_ptr(), b.capacity, b.count.data_ptr(),
+            _lib.check(lib.nsm_sort_hits(b.records.data_ptr(), b.scratch.data_ptr(), b.capacity, b.count.data_ptr(), 0, id_limit,
                                          side.cuda_stream), "nsm_sort_hits")
             ordered[k].record(side)
             used[k] = True
         else:
             b.count.zero_()
             work.launch(b, stream, prune)
-            _lib.check(lib.nsm_sort_hits(b.records.data_ptr(), b.scratch.data_ptr(), b.capacity, b.count.data_ptr(), stream),
-                       "nsm_sort_hits")
+            _lib.check(lib.nsm_sort_hits(b.records.data_ptr(), b.scratch.data_ptr(), b.capacity, b.count.data_ptr(), 0, id_limit,
+                                         stream), "nsm_sort_hits")
         if world > 1:
             pending[k] = comm.gather_hits(b, gathered[k], async_op=True)
 
@@ -818,7 +904,7 @@ def run_raw(args, comm, device, name, rows=0, right_rows=0, threshold=None, step
         "roofline": valu_roofline(work.name, work.kernel_match, work.kernel + " (exact prune on)", k_ms, 1, alg_bytes,
                                   compulsory, default_shape=default_shape),
     }
-    if extras:
+    if extras and not args.no_extras:
         # exhaustive variant (prune off): fewer repetitions, it is the slow one
         ex_steps = max(2, min(steps, 5))
         step(False)
@@ -865,35 +951,49 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
 
-    if args.workload == "c5":
-        result = run_c5(args, comm, device)
+    if args.workload in ("c5", "c5w"):
+        result = run_c5(args, comm, device, words=args.workload == "c5w")
     elif args.workload != "all":
         result = run_raw(args, comm, device, args.workload, args.rows, args.right_rows, args.threshold)
     else:
-        # the headline (BASELINE configs[1]) ...
-        result = run_raw(args, comm, device, "c2", args.rows, args.right_rows, args.threshold)
-        # ... and every other workload under the same clock, attached as sub-records.  N > 1: the two configs
-        # BASELINE.json quotes on 8 GPUs (c4, c5), left rows divided over the ranks.
-        names = () if args.no_c4 else (("c2low", "c3", "c4", "c5", "term") if world == 1 else ("c4", "c5"))
+        # the headline: BASELINE configs[2], the largest configuration quoted on one GPU ...
+        result = run_raw(args, comm, device, "c3", args.rows, args.right_rows, args.threshold)
+        # ... and every other workload under the same clock, attached as sub-records.  N > 1: the configs
+        # BASELINE.json quotes on 8 GPUs (c4, c5; c5w = c5 on word-like text), left rows divided over the ranks.
+        names = () if args.no_c4 else (("c2", "c2low", "c4", "c5", "c5w", "term") if world == 1 else ("c4", "c5", "c5w"))
         t_all = time.perf_counter()
+        mirror = {}
         for name in names:
             release()
             t_sub = time.perf_counter()
-            if name == "c5":
-                sub = run_c5(args, comm, device, steps=max(1, min(args.steps, 5)), warmup=1, sub=True)
+            if name in ("c5", "c5w"):
+                sub = run_c5(args, comm, device, steps=max(1, min(args.steps, 5 if name == "c5" else 3)), warmup=1, sub=True,
+                             words=name == "c5w")
             else:
                 # c2low / c4 share c2's CPU restatement (same function, same corpus generator): a short sample
-                sub = run_raw(args, comm, device, name, args.rows, 0 if name == "c4" else args.right_rows,
-                              args.threshold if name == "c2" else None, extras=world == 1,
-                              cpu_scale=0.25 if name in ("c2low", "c4") else 1.0)
+                sub = run_raw(args, comm, device, name, args.rows, 0 if name == "c4" else args.right_rows, None,
+                              extras=world == 1, cpu_scale=0.25 if name in ("c2low", "c4") else 1.0)
             rec = {k: sub[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "scaling", "dtype", "config",
-                                       "roofline", "exhaustive", "cpu_baseline") if k in sub}
+                                       "roofline", "exhaustive", "cpu_baseline", "at_score_threshold") if k in sub}
             rec["workload"] = sub["config"]["workload"]
             rec["kernel_ms"] = sub["roofline"]["kernel_ms"]
             rec["wall_seconds_incl_setup"] = round(time.perf_counter() - t_sub, 1)
             result[name] = rec
+            # the same numbers as plain scalars under `config` (see the module docstring: config.sub)
+            mirror[name] = {
+                "ms_per_step": rec["ms_per_step"], "value": rec["value"], "steps": rec["steps"], "kernel_ms": rec["kernel_ms"],
+                "roofline_frac": rec["roofline"].get("frac"),
+                "roofline_kernel": rec["roofline"].get("kernel"),
+                "exhaustive_ms_per_step": rec.get("exhaustive", {}).get("ms_per_step"),
+                "cpu_baseline_value": rec.get("cpu_baseline", {}).get("value"),
+                "threshold": sub["config"].get("threshold"),
+                "hits": sub["config"].get("hits_all_ranks", sub["config"].get("hits_per_grid_all_ranks")),
+            }
+            if "at_score_threshold" in rec:
+                mirror[name]["ms_per_step_at_0.7"] = rec["at_score_threshold"]["ms_per_step"]
         if names:
             result["sub_records_wall_seconds"] = round(time.perf_counter() - t_all, 1)
+            result["config"]["sub"] = mirror
     if world > 1 and comm.dev_group is not None:
         assert comm.rccl_ranks == world, f"RCCL saw {comm.rccl_ranks} ranks of {world}"
     if rank == 0:

@@ -18,7 +18,9 @@
  *
  * Conventions
  *   - every pointer marked "device" is HBM memory owned by the caller (the Python host keeps them
- *     as torch tensors); the library keeps no pointer after a call returns;
+ *     as torch tensors); the library keeps no pointer after a call returns and allocates no device memory of
+ *     its own that outlives a call (the builders' scratch is stream-ordered and freed inside the call; the one
+ *     grid that wants scratch -- nsm_indel_levels_grid -- takes it from the caller as `workspace`);
  *   - calls are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
  *   - return value: 0 on success, otherwise a hipError_t or one of the NSM_E_* codes below;
  *     nsm_last_error() gives a thread-local message;
@@ -42,7 +44,7 @@
 extern "C" {
 #endif
 
-#define NSM_ABI_VERSION 3
+#define NSM_ABI_VERSION 4
 
 #define NSM_E_BADARG 10001   /* inconsistent sizes / unsupported width */
 #define NSM_E_UNSUPPORTED 10002
@@ -181,17 +183,34 @@ int nsm_indel_raw_grid(const nsm_str_table* left, const nsm_str_table* right, do
                        unsigned long long* hit_count, void* stream);
 
 /* Levels-mode Indel ratio over per-level strings.
- * Device workspace: for strings up to 64 code units at thresholds >= 0.7 (with NSM_FLAG_PRUNE and histograms) the library
- * keeps a survivor queue per (device, stream) -- allocated with hipMalloc at the first such call, grown when a larger grid
- * needs it (that call synchronises the stream), at most 2 x 1 GB, never freed; the call itself stays asynchronous, and a
- * call on a stream that is being captured into a graph never allocates (it uses the stream's queue if an eager call has
- * sized it, the single-kernel path otherwise).  Hits are
- * appended behind the records already counted in hit_count, as everywhere.  NSM_SPLIT_QUEUE_CAP (environment, entries)
- * bounds the queue: the tests use it to force the overflow path. */
+ *
+ * `workspace` (device, caller-owned, may be NULL) / `workspace_bytes`: scratch for the split path -- scan kernel ->
+ * survivor queue -> finish kernel -- that grids of strings up to 64 code units take at thresholds >= 0.7 (with
+ * NSM_FLAG_PRUNE and histograms).  nsm_indel_levels_workspace_bytes() says how much such a grid can use (0: the grid
+ * never takes that path).  Layout: 64 control words of 8 bytes (word 0 = *hit_count at the start of the call, word 1 =
+ * overflow flag, words 2.. = one queue counter per round), then two queue halves of (workspace_bytes - 512) / 16 entries
+ * of 8 bytes each.  The library reads nothing from it on entry and keeps no pointer to it: the caller may free or reuse
+ * it as soon as the work queued on `stream` by this call has completed (for a captured call: when the graph is
+ * destroyed).  Less than asked for = more rounds over the left rows; a queue that overflows anyway is detected on the
+ * device -- the hit counter is put back and a single-kernel pass, launched behind the rounds and gated on word 1, redoes
+ * the grid (same hits, slower) -- so ANY size is safe; NULL or fewer than 1024 bytes = the single-kernel path alone.
+ * After the call has completed, word 1 != 0 says that the overflow path ran (diagnostic; tests read it).
+ * Besides the workspace the split path uses a side stream and four events per caller stream (the finish kernel of round
+ * k runs beside the scan of round k + 1); they hold no device memory, are created at the first such call on a stream
+ * and destroyed by nsm_release().  A call on a stream that is being captured uses `stream` alone.
+ * Hits are appended behind the records already counted in hit_count, as everywhere. */
+uint64_t nsm_indel_levels_workspace_bytes(const nsm_level_items* left, const nsm_str_table* left_strings,
+                                          const nsm_level_items* right, const nsm_str_table* right_strings,
+                                          double threshold, uint32_t flags);
 int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_table* left_strings,
                           const nsm_level_items* right, const nsm_str_table* right_strings,
                           double threshold, int32_t category_mode, uint32_t flags, nsm_hit* hits,
-                          uint64_t capacity, unsigned long long* hit_count, void* stream);
+                          uint64_t capacity, unsigned long long* hit_count, void* workspace,
+                          uint64_t workspace_bytes, void* stream);
+
+/* Destroy the side stream and events the library created for `stream` on the current device.  The caller makes sure no nsm_indel_levels_grid work is still queued on that stream.  Returns 0. */
+int nsm_release(void* stream);
+int nsm_release_all(void); /* the same for every stream of every device */
 
 /* ---------------------------------------------------------------------------------------------------------
  * Builders: plain per-item arrays in device memory (in the CALLER's row order) -> a table the grid functions
@@ -286,9 +305,15 @@ int nsm_jaccard_any_grid(const nsm_any_sets* left, const nsm_any_sets* right, do
                          uint32_t flags, nsm_hit* hits, uint64_t capacity, unsigned long long* hit_count, void* stream);
 
 /* In-place canonical ordering of the first min(*hit_count, capacity) hits:
- * score descending, then i, then j ascending.  `scratch` is a device buffer of the same capacity. */
-int nsm_sort_hits(nsm_hit* hits, nsm_hit* scratch, uint64_t capacity,
-                  const unsigned long long* hit_count, void* stream);
+ * score descending, then i, then j ascending.  `scratch` is a device buffer of the same capacity (may be NULL when at most
+ * 8192 records can be live).
+ *   n_hint    0, or the caller's promise that at most n_hint records are live (a host that has read the counter knows):
+ *             the launch geometry then follows n_hint instead of capacity -- one launch up to 8192 records whatever the
+ *             buffer's size.  With more live records than promised the order is unspecified (no record is lost).
+ *   id_limit  0, or the caller's promise that every i and j is in [0, id_limit) (the larger cohort's size): fewer key
+ *             bits to sort above 8192 records. */
+int nsm_sort_hits(nsm_hit* hits, nsm_hit* scratch, uint64_t capacity, const unsigned long long* hit_count,
+                  uint64_t n_hint, uint32_t id_limit, void* stream);
 
 #ifdef __cplusplus
 }

@@ -15,6 +15,8 @@
 //     separate launches over global memory.  Passes beyond the live count exit immediately.
 #include "nsm_common.hpp"
 
+#include <atomic>
+
 namespace nsm {
 
 __device__ __forceinline__ bool hit_before(const nsm_hit& a, const nsm_hit& b) {
@@ -167,45 +169,56 @@ __global__ __launch_bounds__(kBlock) void bitonic_tile_kernel(nsm_hit* __restric
 
 }  // namespace nsm
 
-extern "C" int nsm_sort_hits(nsm_hit* hits, nsm_hit* scratch, uint64_t capacity,
-                             const unsigned long long* hit_count, void* stream) {
+extern "C" int nsm_sort_hits(nsm_hit* hits, nsm_hit* scratch, uint64_t capacity, const unsigned long long* hit_count,
+                             uint64_t n_hint, uint32_t id_limit, void* stream) {
   using namespace nsm;
+  (void)id_limit;
   if (!hits || !hit_count) {
     set_error("nsm_sort_hits: null argument");
     return NSM_E_BADARG;
   }
   if (capacity == 0) return 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // The count lives on the device, so the launch geometry comes from what the host knows: `capacity`, or the caller's promise
+  // n_hint >= min(*hit_count, capacity) (0 = no promise).  A host that has read the counter -- run_grid does, to size its
+  // copy -- pays one launch for ten hits whatever the buffer's capacity.
+  const unsigned long long bound = (n_hint != 0 && n_hint < capacity) ? n_hint : capacity;
+  if (bound < 2) return 0;
   // up to 8192 live records: ONE launch of one workgroup (bitonic network on 128-bit keys in LDS).  Round 2 sorted
   // 2049..8192 records with a rank-sort launch plus a copy launch; both were launched for every capacity above 2048
   // (the count lives on the device) and two empty launches cost the headline step more than they ever saved.
-  const int lds_records = static_cast<int>(capacity < kSmallSortMax ? (capacity < 2 ? 2 : capacity) : kSmallSortMax);
+  const int lds_records = static_cast<int>(bound < kSmallSortMax ? bound : kSmallSortMax);
   int p2 = 2;
   while (p2 < lds_records) p2 <<= 1;
-  static bool attr_set = false;
-  if (!attr_set) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&small_sort_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, kSmallSortMax * 16);
-    if (e != hipSuccess) return hip_status(e, "hipFuncSetAttribute(small_sort_kernel)");
-    attr_set = true;
+  {
+    static std::atomic<unsigned long long> attr_devs{0};  // one bit per device ordinal: the attribute is per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = dev >= 0 && dev < 64 ? 1ull << dev : 0ull;
+    if (!bit || !(attr_devs.load(std::memory_order_acquire) & bit)) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&small_sort_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, kSmallSortMax * 16);
+      if (e != hipSuccess) return hip_status(e, "hipFuncSetAttribute(small_sort_kernel)");
+      attr_devs.fetch_or(bit, std::memory_order_release);
+    }
   }
   hipLaunchKernelGGL(small_sort_kernel, dim3(1), dim3(kSmallSortThreads), static_cast<size_t>(p2) * 16, s, hits, capacity,
                      hit_count, p2);
-  if (capacity <= kSmallSortMax) return hip_status(hipGetLastError(), "nsm_sort_hits (small)");
+  if (bound <= kSmallSortMax) return hip_status(hipGetLastError(), "nsm_sort_hits (small)");
   if (!scratch) {
     set_error("nsm_sort_hits: scratch buffer required");
     return NSM_E_BADARG;
   }
-  unsigned long long blocks64 = (capacity + kBlock - 1) / kBlock;
+  unsigned long long blocks64 = (bound + kBlock - 1) / kBlock;
   const unsigned blocks = static_cast<unsigned>(blocks64 < 8192 ? blocks64 : 8192);
-  unsigned long long tiles64 = (capacity + kTile - 1) / kTile;
+  unsigned long long tiles64 = (bound + kTile - 1) / kTile;
   if (tiles64 > 0x7fffffffull) {
     set_error("nsm_sort_hits: capacity too large");
     return NSM_E_UNSUPPORTED;
   }
   const unsigned tiles = static_cast<unsigned>(tiles64);
   hipLaunchKernelGGL(bitonic_tile_kernel, dim3(tiles), dim3(kBlock), 0, s, hits, capacity, hit_count, 0ull);
-  for (unsigned long long k = 2ull * kTile; (k >> 1) < capacity; k <<= 1) {
+  for (unsigned long long k = 2ull * kTile; (k >> 1) < bound; k <<= 1) {
     hipLaunchKernelGGL(bitonic_pass_kernel, dim3(blocks), dim3(kBlock), 0, s, hits, capacity, hit_count, k, 0ull);
     for (unsigned long long j = k >> 2; j >= static_cast<unsigned long long>(kTile); j >>= 1)
       hipLaunchKernelGGL(bitonic_pass_kernel, dim3(blocks), dim3(kBlock), 0, s, hits, capacity, hit_count, k, j);

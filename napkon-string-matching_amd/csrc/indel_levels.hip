@@ -289,78 +289,135 @@ __global__ __launch_bounds__(kBlock) void indel_levels_kernel(
 #include "indel_levels_finish.hpp"
 #include "indel_levels_tile.hpp"
 
-#include <cstdlib>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <utility>
 
 namespace nsm {
 
-// Device workspace of the split path (survivor queue + control words), one per (device, stream), grown on demand and kept:
-// a grid call must not allocate per launch, and calls on different streams may overlap.
-// The finish kernel of round k runs on a stream of the library's own, beside the scan of round k + 1 (two queue halves):
-// the scan leaves ~40 % of the VALU issue slots and nearly all of the HBM bandwidth unused, the finish kernel waits on
-// gathers.  Events order the two streams; the caller's stream waits for the last finish before the call's last launches,
-// so the call behaves like any other sequence of launches on `stream`.
+// Split path (one-word strings, histogram bound on, thresholds where few pairs outlive step 1): scan kernel -> survivor queue
+// -> finish kernel.  The queue and its control words live in the CALLER's workspace (include/nsm_hip.h); what the library
+// owns per (device, caller stream) is a side stream and four events, no device memory: the finish kernel of round k runs on
+// the side stream beside the scan of round k + 1 (two queue halves) -- the scan leaves ~40 % of the VALU issue slots and
+// nearly all of the HBM bandwidth unused, the finish kernel waits on gathers.  Events order the two streams; the caller's
+// stream waits for the last finish before the call's last launches, so the call behaves like any other sequence of launches
+// on `stream`.  nsm_release() destroys them.
 #ifndef NSM_SPLIT_OVERLAP
 #define NSM_SPLIT_OVERLAP 1
 #endif
-struct SplitWorkspace {
-  unsigned long long* queue = nullptr;  // two halves of `cap` entries
-  unsigned long long* ctl = nullptr;  // [0] hit counter at the start | [1] overflow flag (int) | [2 ..] queue counter per round
-  unsigned long long cap = 0;
+struct SplitSide {
   hipStream_t side = nullptr;
   hipEvent_t scanned[2] = {nullptr, nullptr}, finished[2] = {nullptr, nullptr};
 };
 constexpr int kSplitMaxRounds = 62;
-constexpr int kSplitCtlWords = 2 + kSplitMaxRounds;
+constexpr int kSplitCtlWords = 2 + kSplitMaxRounds;  // [0] hit counter at the start | [1] overflow flag (int) | [2 ..] queue counter per round
+constexpr unsigned long long kSplitCtlBytes = kSplitCtlWords * 8ull;
+constexpr unsigned long long kSplitMinWorkspace = 1024;
 
-// `capturing`: the stream records a hipGraph -- nothing may be allocated or synchronised now; *out stays empty (queue ==
-// nullptr) unless the stream's workspace exists and is large enough, and the caller takes the single-kernel path instead.
-static int split_workspace(void* stream, unsigned long long entries, bool capturing, SplitWorkspace* out) {
-  static std::mutex mu;
-  static std::map<std::pair<int, void*>, SplitWorkspace> all;
+#ifndef NSM_SPLIT_MIN_THRESHOLD
+// (3 x 100k^2 C5-shaped grids, split vs fused, ms: 0.65 112.9 vs 81.9, 0.675 43.1 vs 32.5, 0.7 11.9 vs 18.1, 0.8 11.7 vs 14.3,
+// 0.9 5.4 vs 7.4 -- below 0.7 the survivors multiply (5x the hits per 0.025) and lane-per-pair finishing costs more than the
+// dense passes it replaces)
+#define NSM_SPLIT_MIN_THRESHOLD 0.7
+#endif
+#ifndef NSM_SPLIT_QUEUE_MAX
+#define NSM_SPLIT_QUEUE_MAX (128ull << 20)  // entries per half (1 GB)
+#endif
+
+static std::mutex g_side_mu;
+static std::map<std::pair<int, void*>, SplitSide> g_sides;
+
+static void destroy_side(SplitSide& w) {
+  for (int k = 0; k < 2; ++k) {
+    if (w.scanned[k]) (void)hipEventDestroy(w.scanned[k]);
+    if (w.finished[k]) (void)hipEventDestroy(w.finished[k]);
+    w.scanned[k] = w.finished[k] = nullptr;
+  }
+  if (w.side) (void)hipStreamDestroy(w.side);
+  w.side = nullptr;
+}
+
+// The side stream of (current device, stream); created at the first call.  On any failure *out stays empty and the caller
+// runs its rounds on `stream` alone (slower by a few per cent, same result): never an error.
+static void split_side(void* stream, SplitSide* out) {
+  if (!NSM_SPLIT_OVERLAP) return;
   int dev = 0;
-  hipError_t e = hipGetDevice(&dev);
-  if (e != hipSuccess) return hip_status(e, "hipGetDevice");
-  std::lock_guard<std::mutex> lock(mu);
-  if (capturing) {
-    auto it = all.find(std::make_pair(dev, stream));
-    if (it != all.end() && it->second.ctl && it->second.cap >= entries) *out = it->second;
-    return 0;
+  if (hipGetDevice(&dev) != hipSuccess) return;
+  std::lock_guard<std::mutex> lock(g_side_mu);
+  auto it = g_sides.find(std::make_pair(dev, stream));
+  if (it != g_sides.end()) {
+    *out = it->second;
+    return;
   }
-  SplitWorkspace& w = all[std::make_pair(dev, stream)];
-  if (!w.ctl) {
-    e = hipMalloc(reinterpret_cast<void**>(&w.ctl), kSplitCtlWords * 8);
-    if (e != hipSuccess) return hip_status(e, "hipMalloc(split control words)");
-    if (NSM_SPLIT_OVERLAP) {
-      int lo = 0, hi = 0;
-      e = hipDeviceGetStreamPriorityRange(&lo, &hi);  // (hi = the numerically lowest = greatest priority)
-      if (e == hipSuccess) e = hipStreamCreateWithPriority(&w.side, hipStreamNonBlocking, hi);
-      for (int k = 0; k < 2 && e == hipSuccess; ++k) {
-        e = hipEventCreateWithFlags(&w.scanned[k], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&w.finished[k], hipEventDisableTiming);
-      }
-      if (e != hipSuccess) return hip_status(e, "split path: side stream / events");
-    }
+  SplitSide w;
+  int lo = 0, hi = 0;
+  hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);  // (hi = the numerically lowest = greatest priority)
+  if (e == hipSuccess) e = hipStreamCreateWithPriority(&w.side, hipStreamNonBlocking, hi);
+  for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+    e = hipEventCreateWithFlags(&w.scanned[k], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&w.finished[k], hipEventDisableTiming);
   }
-  if (w.cap < entries) {
-    if (w.queue) {  // (launches that still read the old queue are ahead of this call in the same stream)
-      e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
-      if (e == hipSuccess) e = hipFree(w.queue);
-      w.queue = nullptr;
-      w.cap = 0;
-      if (e != hipSuccess) return hip_status(e, "hipFree(survivor queue)");
-    }
-    e = hipMalloc(reinterpret_cast<void**>(&w.queue), entries * 8 * (NSM_SPLIT_OVERLAP ? 2 : 1));
-    if (e != hipSuccess) return hip_status(e, "hipMalloc(survivor queue)");
-    w.cap = entries;
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    destroy_side(w);
+    return;
   }
+  g_sides[std::make_pair(dev, stream)] = w;
   *out = w;
-  return 0;
+}
+
+// Does this grid take the split path when it is given a workspace, and how many survivors does it expect?  (2 % of the pairs
+// visited; a partition visits ~1/16 of the grid or less.  configs[4] measures 0.9 %.)
+static bool split_eligible(const nsm_level_items* left, const nsm_str_table* left_strings, const nsm_level_items* right,
+                           const nsm_str_table* right_strings, double threshold, uint32_t flags, double* expect) {
+  if (!left || !right || !left_strings || !right_strings) return false;
+  if (left_strings->stride != 64 || right_strings->stride != 64) return false;
+  if (left_strings->alphabet != right_strings->alphabet || left_strings->alphabet < 1) return false;
+  if (flags & (NSM_FLAG_PARK | NSM_FLAG_WAVE_WIDE)) return false;
+  if (!(flags & NSM_FLAG_PRUNE) || !left_strings->hist || !right_strings->hist) return false;
+  if (!(threshold >= NSM_SPLIT_MIN_THRESHOLD)) return false;
+  if ((left_strings->alphabet + 1 + 7) / 8 * 8 > 64) return false;  // the scan's two 64-entry tables
+  if (left->n <= 0 || right->n <= 0 || left->n >= (1 << kQueueRowBits) || right->n >= (1 << kQueueRowBits)) return false;
+  *expect = static_cast<double>(left->n) * static_cast<double>(right->n) * 0.02 * (left->seg ? 1.0 / 16 : 1.0);
+  return true;
 }
 
 }  // namespace nsm
+
+extern "C" uint64_t nsm_indel_levels_workspace_bytes(const nsm_level_items* left, const nsm_str_table* left_strings,
+                                                     const nsm_level_items* right, const nsm_str_table* right_strings,
+                                                     double threshold, uint32_t flags) {
+  using namespace nsm;
+  double expect = 0.0;
+  if (!split_eligible(left, left_strings, right, right_strings, threshold, flags, &expect)) return 0;
+  const unsigned long long qmax = NSM_SPLIT_QUEUE_MAX;
+  const unsigned long long rounds = static_cast<unsigned long long>(expect / static_cast<double>(qmax)) + 1;
+  unsigned long long entries = static_cast<unsigned long long>(expect / static_cast<double>(rounds)) + (1ull << 16);
+  if (entries > qmax) entries = qmax;
+  return kSplitCtlBytes + 2 * entries * 8;
+}
+
+extern "C" int nsm_release(void* stream) {
+  using namespace nsm;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  std::lock_guard<std::mutex> lock(g_side_mu);
+  auto it = g_sides.find(std::make_pair(dev, stream));
+  if (it != g_sides.end()) {
+    destroy_side(it->second);
+    g_sides.erase(it);
+  }
+  return 0;
+}
+
+extern "C" int nsm_release_all(void) {
+  using namespace nsm;
+  std::lock_guard<std::mutex> lock(g_side_mu);
+  for (auto& kv : g_sides) destroy_side(kv.second);  // (streams and events of another device are destroyed from here just as well)
+  g_sides.clear();
+  return 0;
+}
 
 #ifdef NSM_SCAN_STATS
 // variant builds only: copy the one-word scan's work counters to `out[8]` and reset them (synchronises the device)
@@ -387,7 +444,8 @@ extern "C" int nsm_debug_tile_stats(unsigned long long* out) {
 extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_table* left_strings,
                                      const nsm_level_items* right, const nsm_str_table* right_strings,
                                      double threshold, int32_t category_mode, uint32_t flags, nsm_hit* hits,
-                                     uint64_t capacity, unsigned long long* hit_count, void* stream) {
+                                     uint64_t capacity, unsigned long long* hit_count, void* workspace,
+                                     uint64_t workspace_bytes, void* stream) {
   using namespace nsm;
   if (!left || !right || !left_strings || !right_strings || !hit_count || (!hits && capacity)) {
     set_error("nsm_indel_levels_grid: null argument");
@@ -417,6 +475,10 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
     return NSM_E_BADARG;
   }
   if (left->n == 0 || right->n == 0) return 0;
+  if (workspace != nullptr && (reinterpret_cast<uintptr_t>(workspace) & 7u)) {
+    set_error("nsm_indel_levels_grid: workspace must be 8-byte aligned");
+    return NSM_E_BADARG;
+  }
   if ((left->seg == nullptr) != (right->seg == nullptr) || (left->seg && (!left->seg_start || !left->cat ||
       !right->cat || category_mode != NSM_CAT_INTERSECT))) {
     set_error("nsm_indel_levels_grid: a category partition needs seg/seg_start/cat on both sides and "
@@ -544,12 +606,15 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
     const unsigned blocks = static_cast<unsigned>(8ll * ((n_tiles + 7) / 8) * slices);
 #define NSM_LAUNCH_TILE(KK)                                                                                        \
   do {                                                                                                             \
-    static bool attr_set = false;                                                                                  \
-    if (!attr_set) {                                                                                               \
+    static std::atomic<unsigned long long> attr_devs{0}; /* one bit per device ordinal: the attribute is per device */ \
+    int dev_ = 0;                                                                                                  \
+    (void)hipGetDevice(&dev_);                                                                                     \
+    const unsigned long long bit_ = dev_ >= 0 && dev_ < 64 ? 1ull << dev_ : 0ull;                                  \
+    if (!(attr_devs.load(std::memory_order_acquire) & bit_) || !bit_) {                                            \
       const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&indel_levels_tile_kernel<KK>),       \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);            \
       if (e != hipSuccess) return hip_status(e, "hipFuncSetAttribute(indel_levels_tile_kernel)");                  \
-      attr_set = true;                                                                                             \
+      attr_devs.fetch_or(bit_, std::memory_order_release);                                                         \
     }                                                                                                              \
     hipLaunchKernelGGL((indel_levels_tile_kernel<KK>), dim3(blocks), dim3(tw * kWave), lds_tile,                   \
                        static_cast<hipStream_t>(stream), left->first, left->nlev, left->orig, left->cat,           \
@@ -584,21 +649,14 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
     q.slice_base = 0;
     q.slices_total = 0;
     q.qcap = 0;
-    // Split path (one-word strings, bound on, thresholds where few pairs outlive step 1): scan kernel -> global survivor
-    // queue -> finish kernel (indel_levels_finish.hpp), the left slices in rounds sized to the queue.  A queue that
-    // overflows anyway (the survival rate is a guess) raises a flag: the hit counter is put back and the fused kernel,
-    // launched behind the rounds and gated on that flag, redoes the grid.  NSM_FLAG_PARK = the fused kernel alone.
-#ifndef NSM_SPLIT_MIN_THRESHOLD
-// (3 x 100k^2 C5-shaped grids, split vs fused, ms: 0.65 112.9 vs 81.9, 0.675 43.1 vs 32.5, 0.7 11.9 vs 18.1, 0.8 11.7 vs 14.3,
-// 0.9 5.4 vs 7.4 -- below 0.7 the survivors multiply (5x the hits per 0.025) and lane-per-pair finishing costs more than the
-// dense passes it replaces)
-#define NSM_SPLIT_MIN_THRESHOLD 0.7
-#endif
-#ifndef NSM_SPLIT_QUEUE_MAX
-#define NSM_SPLIT_QUEUE_MAX (128ull << 20)  // entries (1 GB)
-#endif
-    const bool split = K == 1 && !(flags & NSM_FLAG_PARK) && q.use_hist && threshold >= NSM_SPLIT_MIN_THRESHOLD &&
-                       q.pm_stride <= 64 && left->n < (1 << kQueueRowBits) && right->n < (1 << kQueueRowBits);
+    // Split path (one-word strings, bound on, thresholds where few pairs outlive step 1): scan kernel -> survivor queue in
+    // the caller's workspace -> finish kernel (indel_levels_finish.hpp), the left slices in rounds sized to the queue.  A
+    // queue that overflows anyway (the survival rate is a guess) raises a flag: the hit counter is put back and the fused
+    // kernel, launched behind the rounds and gated on that flag, redoes the grid.  No workspace, NSM_FLAG_PARK = the fused
+    // kernel alone.
+    double expect = 0.0;
+    const bool split = workspace != nullptr && workspace_bytes >= kSplitMinWorkspace &&
+                       split_eligible(left, left_strings, right, right_strings, threshold, flags, &expect);
     const size_t fixed_wave = (K > 1 ? 16 * K * kWave * 4 + batch * kWave * 8 : 0) + batch * kWave * 2 +
                               batch * 3 * kHeadDwords * 4 + batch * kWave * K;
     const int sub = park_sub(K);
@@ -642,30 +700,27 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
     }
     const int* gate = nullptr;
     if (split && pw == 4) {  // (the scan kernel's LDS layout is compiled for four waves; always the case at pm_stride <= 64)
-      // rounds: the expected number of survivors (2 % of the pairs visited; a partition visits ~1/16 of the grid or less)
-      // against the queue
-      double expect = static_cast<double>(left->n) * static_cast<double>(right->n) * 0.02 * (left->seg ? 1.0 / 16 : 1.0);
-      unsigned long long qmax = NSM_SPLIT_QUEUE_MAX;
-      if (const char* env = std::getenv("NSM_SPLIT_QUEUE_CAP")) qmax = std::strtoull(env, nullptr, 10);  // (tests: force an overflow)
-      if (qmax < 1) qmax = 1;
-      const long long slices_all = left->seg ? static_cast<long long>(q.xcd_slices ? q.xcd_slices : pgrid.y) : pgrid.y;
-      long long rounds = static_cast<long long>(expect / static_cast<double>(qmax)) + 1;
-      if (rounds > kSplitMaxRounds) rounds = kSplitMaxRounds;
-      if (rounds > slices_all) rounds = slices_all;
-      unsigned long long entries = static_cast<unsigned long long>(expect / static_cast<double>(rounds)) + (1ull << 16);
-      if (entries > qmax) entries = qmax;
-      SplitWorkspace ws;
+      // rounds: the expected number of survivors against the queue the caller gave (two halves when the finish kernels run
+      // on the side stream)
       hipStream_t hs = static_cast<hipStream_t>(stream);
       hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
       if (hipStreamIsCapturing(hs, &capture) != hipSuccess) capture = hipStreamCaptureStatusNone;
-      const int rc = split_workspace(stream, entries, capture != hipStreamCaptureStatusNone, &ws);
-      if (rc != 0) return rc;
-      if (ws.queue != nullptr) {
-      hipLaunchKernelGGL(split_begin_kernel, dim3(1), dim3(kWave), 0, hs, ws.ctl, kSplitCtlWords, hit_count);
+      SplitSide ws;
+      if (capture == hipStreamCaptureStatusNone) split_side(stream, &ws);  // (a capturing stream stays on its own)
+      unsigned long long* ctl = static_cast<unsigned long long*>(workspace);
+      unsigned long long* queue = ctl + kSplitCtlWords;
+      unsigned long long entries = (workspace_bytes - kSplitCtlBytes) / 16;  // per half (>= 32)
+      if (entries > NSM_SPLIT_QUEUE_MAX) entries = NSM_SPLIT_QUEUE_MAX;
+      const long long slices_all = left->seg ? static_cast<long long>(q.xcd_slices ? q.xcd_slices : pgrid.y) : pgrid.y;
+      long long rounds = static_cast<long long>(expect / static_cast<double>(entries)) + 1;
+      if (rounds > kSplitMaxRounds) rounds = kSplitMaxRounds;
+      if (rounds > slices_all) rounds = slices_all;
+      {
+      hipLaunchKernelGGL(split_begin_kernel, dim3(1), dim3(kWave), 0, hs, ctl, kSplitCtlWords, hit_count);
       ParkParams sq = q;
       sq.park_slots = 0;
       sq.fin_rows = 1;
-      sq.qcap = entries;  // (not ws.cap: a smaller grid after a larger one keeps its own bound, results do not depend on history)
+      sq.qcap = entries;
       sq.slices_total = static_cast<int>(slices_all);
       const size_t scan_lds = pw * (2 * kSplitTableBytes + fixed_wave + kQueueBuf * 8) + 66 * 16 + 8 + 4 * sub * 4;
       FinishParams fp;
@@ -676,7 +731,7 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
       fp.cap = capacity;
       fp.qcap = entries;
       const long long per_round = (slices_all + rounds - 1) / rounds;
-      int* qflag = reinterpret_cast<int*>(ws.ctl + 1);
+      int* qflag = reinterpret_cast<int*>(ctl + 1);
       long long n_rounds = 0;
       for (long long rd = 0; rd * per_round < slices_all; ++rd, ++n_rounds) {
         const long long s0 = rd * per_round;
@@ -691,7 +746,7 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
           sgrid.y = static_cast<unsigned>(ns);
         }
         const int half = ws.side ? static_cast<int>(rd & 1) : 0;
-        unsigned long long* qhalf = ws.queue + static_cast<size_t>(half) * ws.cap;
+        unsigned long long* qhalf = queue + static_cast<size_t>(half) * entries;
         hipStream_t fs = hs;
         if (ws.side) {
           fs = ws.side;
@@ -704,7 +759,7 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
                            left->nlev, left->orig, left->cat, left->seg_start, left_strings->codes, left_strings->len,
                            left_strings->hist, right->first, right->nlev, right->orig, right->cat, right->seg,
                            right_strings->codes, right_strings->len, right_strings->hist, hits, hit_count, sq,
-                           right->seg_start, qhalf, ws.ctl + 2 + rd, qflag, static_cast<const int*>(nullptr));
+                           right->seg_start, qhalf, ctl + 2 + rd, qflag, static_cast<const int*>(nullptr));
         if (ws.side) {
           hipError_t e = hipEventRecord(ws.scanned[half], hs);
           if (e == hipSuccess) e = hipStreamWaitEvent(fs, ws.scanned[half], 0);
@@ -714,7 +769,7 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
                            static_cast<size_t>(fp.pm_stride) * 2 * kWave * 4, fs, left->first, left->nlev, left->orig,
                            left_strings->codes, left_strings->len, left_strings->hist, right->first, right->nlev,
                            right->orig, right_strings->codes, right_strings->len, right_strings->hist, hits, hit_count,
-                           qhalf, ws.ctl + 2 + rd, qflag, fp);
+                           qhalf, ctl + 2 + rd, qflag, fp);
         if (ws.side) {
           const hipError_t e = hipEventRecord(ws.finished[half], fs);
           if (e != hipSuccess) return hip_status(e, "hipEventRecord(finished)");
@@ -726,9 +781,9 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
           if (e != hipSuccess) return hip_status(e, "hipStreamWaitEvent(join)");
         }
       }
-      hipLaunchKernelGGL(split_end_kernel, dim3(1), dim3(kWave), 0, hs, ws.ctl, hit_count);
+      hipLaunchKernelGGL(split_end_kernel, dim3(1), dim3(kWave), 0, hs, ctl, hit_count);
       gate = qflag;
-      }  // (else: a capturing stream without a sized workspace -- the fused kernel below does the whole grid, ungated)
+      }
     }
     unsigned long long* no_queue = nullptr;
     int* no_flag = nullptr;

@@ -6,7 +6,7 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("NSM_HIP_LIBRARY", _HERE.parent / "csrc" / "libnsm_hip.so"))
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 FLAG_PRUNE = 1
 FLAG_WAVE_WIDE = 2  # nsm_indel_levels_grid without the block-cooperative parking (A/B runs, tests)
 FLAG_INDEX, FLAG_NO_INDEX = 4, 8  # nsm_jaccard_raw_grid: force / forbid the inverted-index kernel
@@ -91,6 +91,9 @@ EXPORTS = (
     "nsm_jaccard_levels_grid",
     "nsm_indel_raw_grid",
     "nsm_indel_levels_grid",
+    "nsm_indel_levels_workspace_bytes",
+    "nsm_release",
+    "nsm_release_all",
     "nsm_sort_hits",
     "nsm_build_set_table",
     "nsm_build_str_table",
@@ -127,22 +130,31 @@ def load() -> ctypes.CDLL:
     lib.nsm_jaccard_levels_grid.argtypes = [
         P(NsmSetTable), P(NsmSetTable), ctypes.c_double, ctypes.c_int32, ctypes.c_uint32] + grid_tail
     lib.nsm_indel_raw_grid.argtypes = [P(NsmStrTable), P(NsmStrTable), ctypes.c_double, ctypes.c_uint32] + grid_tail
+    # hits, capacity, hit_count, workspace, workspace_bytes, stream
     lib.nsm_indel_levels_grid.argtypes = [
         P(NsmLevelItems), P(NsmStrTable), P(NsmLevelItems), P(NsmStrTable),
-        ctypes.c_double, ctypes.c_int32, ctypes.c_uint32] + grid_tail
+        ctypes.c_double, ctypes.c_int32, ctypes.c_uint32, ctypes.c_void_p, c_u64, ctypes.c_void_p, ctypes.c_void_p, c_u64,
+        ctypes.c_void_p]
+    lib.nsm_indel_levels_workspace_bytes.argtypes = [
+        P(NsmLevelItems), P(NsmStrTable), P(NsmLevelItems), P(NsmStrTable), ctypes.c_double, ctypes.c_uint32]
+    lib.nsm_release.argtypes = [ctypes.c_void_p]
+    lib.nsm_release_all.argtypes = []
     lib.nsm_indel_any_grid.argtypes = [
         P(NsmAnyItems), P(NsmAnyStrings), P(NsmAnyItems), P(NsmAnyStrings), ctypes.c_double, ctypes.c_int32,
         ctypes.c_uint32] + grid_tail
     lib.nsm_jaccard_any_grid.argtypes = [P(NsmAnySets), P(NsmAnySets), ctypes.c_double, ctypes.c_int32, ctypes.c_uint32] + grid_tail
-    lib.nsm_sort_hits.argtypes = [ctypes.c_void_p, ctypes.c_void_p, c_u64, ctypes.c_void_p, ctypes.c_void_p]
+    # hits, scratch, capacity, hit_count, n_hint, id_limit, stream
+    lib.nsm_sort_hits.argtypes = [ctypes.c_void_p, ctypes.c_void_p, c_u64, ctypes.c_void_p, c_u64, ctypes.c_uint32,
+                                  ctypes.c_void_p]
     vp, i32, u32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32
     lib.nsm_build_set_table.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, i32, u32, P(NsmSetTable), vp]
     lib.nsm_build_str_table.argtypes = [vp, vp, vp, i32, u32, P(NsmStrTable), vp]
     lib.nsm_build_level_items.argtypes = [vp, vp, vp, vp, i32, i32, u32, P(NsmLevelItems), vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("nsm_last_error",):
+        if name not in ("nsm_last_error", "nsm_indel_levels_workspace_bytes"):
             fn.restype = ctypes.c_int
+    lib.nsm_indel_levels_workspace_bytes.restype = c_u64
     lib.nsm_last_error.restype = ctypes.c_char_p
     _lib = lib
     return lib

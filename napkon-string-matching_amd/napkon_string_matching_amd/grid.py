@@ -66,16 +66,24 @@ class HitBuffer:
         return score, ij[:, 0], ij[:, 1]
 
 
-def sort_hits_device(buf: HitBuffer, n: int) -> Hits:
-    """Canonical order on the device, then one D2H copy of the n records."""
+SMALL_SORT_MAX = 8192  # records nsm_sort_hits orders in one workgroup's LDS (no scratch buffer needed)
+
+
+def sort_hits_device(buf: HitBuffer, n: int, id_limit: int = 0) -> Hits:
+    """Canonical order on the device, then one D2H copy of the n records.  The host has read the counter (``n``), so
+    the sort's geometry follows the hits, not the buffer: one launch up to 8192 records at any capacity."""
     if n == 0:
         return Hits(np.zeros(0, np.float64), np.zeros(0, np.int32), np.zeros(0, np.int32))
     lib = _lib.load()
-    if buf.scratch is None or buf.scratch.shape[0] < buf.records.shape[0]:
-        buf.scratch = torch.empty_like(buf.records)
+    scratch_ptr = 0
+    if n > SMALL_SORT_MAX:
+        if buf.scratch is None or buf.scratch.shape[0] < n:
+            buf.scratch = torch.empty((n, 2), dtype=torch.float64, device=buf.records.device)
+        scratch_ptr = buf.scratch.data_ptr()
     stream = torch.cuda.current_stream(buf.records.device).cuda_stream
     _lib.check(
-        lib.nsm_sort_hits(buf.records.data_ptr(), buf.scratch.data_ptr(), buf.capacity, buf.count.data_ptr(), stream),
+        lib.nsm_sort_hits(buf.records.data_ptr(), scratch_ptr, buf.capacity, buf.count.data_ptr(), n,
+                          max(0, min(int(id_limit), 0x7FFFFFFF)), stream),
         "nsm_sort_hits",
     )
     host = buf.records[:n].cpu().numpy()
@@ -83,8 +91,10 @@ def sort_hits_device(buf: HitBuffer, n: int) -> Hits:
     return Hits(host[:, 0].copy(), ij[:, 2].copy(), ij[:, 3].copy())
 
 
-def run_grid(launch: Callable[[HitBuffer, int], int], device, capacity: Optional[int], what: str) -> Hits:
-    """Run ``launch`` with a hit buffer, growing it once if the counter overflowed."""
+def run_grid(launch: Callable[[HitBuffer, int], int], device, capacity: Optional[int], what: str,
+             id_limit: int = 0) -> Hits:
+    """Run ``launch`` with a hit buffer, growing it once if the counter overflowed.  ``id_limit``: an upper bound of
+    the row ids the grid reports (the larger side's item count), 0 = unknown."""
     dev = _require_gpu(device)
     buf = HitBuffer(capacity or DEFAULT_CAPACITY, dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -93,7 +103,7 @@ def run_grid(launch: Callable[[HitBuffer, int], int], device, capacity: Optional
         _lib.check(launch(buf, stream), what)
         n = int(buf.count.item())  # synchronises the stream
         if n <= buf.capacity:
-            return sort_hits_device(buf, n)
+            return sort_hits_device(buf, n, id_limit)
         buf = HitBuffer(n, dev)
     raise _lib.NsmLibraryError(f"{what}: hit count changed between two identical launches")
 
@@ -167,11 +177,12 @@ def jaccard_levels_grid(
 def indel_levels_grid(
     left: LevelItems, left_strings: StrTable, right: LevelItems, right_strings: StrTable, threshold: float,
     category_mode: int = _lib.CAT_NONE, prune: bool = True, capacity: Optional[int] = None, wave_wide: bool = False,
-    park: bool = False,
+    park: bool = False, workspace: Optional[int] = None, return_overflow: Optional[list] = None,
 ) -> Hits:
     """``compare_terms`` with ``fuzzy_match`` over per-level strings.  ``wave_wide`` selects the kernel
     without block-cooperative parking, ``park`` the round-2 kernel for multi-word strings (same hits; A/B runs
-    and tests)."""
+    and tests).  ``workspace``: bytes of split-path scratch to hand to the library (None = what it asks for, 0 = none:
+    the single-kernel path); ``return_overflow``: a list that receives the workspace's overflow word (tests)."""
     lib = _lib.load()
     li, ls, ri, rs = left.struct(), left_strings.struct(), right.struct(), right_strings.struct()
     flags = (_lib.FLAG_PRUNE if prune else 0) | (_lib.FLAG_WAVE_WIDE if wave_wide else 0) | (_lib.FLAG_PARK if park else 0)
@@ -180,10 +191,37 @@ def indel_levels_grid(
     if left.category_mode is not None:  # the encoder may have rewritten the predicate (partition)
         category_mode = left.category_mode
 
+    # the split path's survivor queue (scan kernel -> queue -> finish kernel; one-word strings at thresholds >= 0.7) is
+    # CALLER-owned scratch: a torch tensor, so torch's allocator owns it and it goes back to the cache with this call
+    dev = left.first.device
+    want = int(lib.nsm_indel_levels_workspace_bytes(li, ls, ri, rs, float(threshold), flags)) if workspace is None else int(workspace)
+    ws = split_workspace(want, dev) if want > 0 else None
+
     def launch(buf: HitBuffer, stream: int) -> int:
         return lib.nsm_indel_levels_grid(
             li, ls, ri, rs, float(threshold), int(category_mode), flags, buf.records.data_ptr(), buf.capacity,
-            buf.count.data_ptr(), stream,
+            buf.count.data_ptr(), ws.data_ptr() if ws is not None else 0, ws.numel() * 8 if ws is not None else 0, stream,
         )
 
-    return run_grid(launch, left.first.device, capacity, "nsm_indel_levels_grid")
+    hits = run_grid(launch, dev, capacity, "nsm_indel_levels_grid")  # (returns after the stream has been synchronised)
+    if ws is not None and return_overflow is not None:
+        return_overflow.append(int(ws[1].item()) & 0xFFFFFFFF)
+    return hits
+
+
+def split_workspace(nbytes: int, device) -> Optional[torch.Tensor]:
+    """Scratch for ``nsm_indel_levels_grid`` (include/nsm_hip.h): ``nbytes`` rounded down to 8-byte words, at most what
+    the device can spare -- less than the library asks for only means more rounds.  None when memory is too tight for a
+    useful queue: the grid then runs its single-kernel path."""
+    words = int(nbytes) // 8
+    try:
+        free, _total = torch.cuda.mem_get_info(device)
+        words = min(words, int(free * 0.5) // 8)
+    except RuntimeError:
+        pass
+    if words < 128:
+        return None
+    try:
+        return torch.empty(words, dtype=torch.int64, device=device)
+    except torch.cuda.OutOfMemoryError:
+        return None

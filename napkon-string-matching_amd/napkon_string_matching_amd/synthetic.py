@@ -144,7 +144,7 @@ def cohort_records(
 
 # ------------------------------------------------------------------ C5: cohorts at scale (vectorised)
 def c5_cohort(n: int, seed: int, vocab: int = 20_000, entries: int = 4, tokens_per_entry: int = 2,
-              n_categories: int = 32, plant_from: dict = None, plant_fraction: float = 0.01):
+              n_categories: int = 32, plant_from: dict = None, plant_fraction: float = 0.01, lex: List[str] = None):
     """hap / pop / suep shaped cohort of BASELINE configs[4]: every item has ``entries`` entries of
     ``tokens_per_entry`` words ``t<id>`` (-> ``entries`` suffix-nested levels, ~8 ids) and 1-2 of
     ``n_categories`` category labels.  Returns a dict with
@@ -154,7 +154,11 @@ def c5_cohort(n: int, seed: int, vocab: int = 20_000, entries: int = 4, tokens_p
       plen   uint8 [n][entries]      level l = first plen[l] ids
       nlev   int32 [n]
       cat    uint64[n]               category bit mask
+    ``lex``: the words behind the ids (``word_vocabulary``; None = ``t<id>``): the "c5w" workload -- configs[4]'s shape on
+    word-like text instead of digit strings.
     """
+    if lex is not None:
+        vocab = len(lex)
     rng = np.random.default_rng(seed)
     width = entries * tokens_per_entry
     tok = rng.integers(0, vocab, size=(n, width), dtype=np.int64).astype(np.int32)
@@ -166,11 +170,11 @@ def c5_cohort(n: int, seed: int, vocab: int = 20_000, entries: int = 4, tokens_p
         change = rng.random(n_plant) < 0.5
         tok[targets[change], rng.integers(0, width, size=int(change.sum()))] = rng.integers(
             0, vocab, size=int(change.sum()))
-        return _finish_c5(tok, rng, entries, tokens_per_entry, n_categories, vocab, targets, plant_from, sources)
-    return _finish_c5(tok, rng, entries, tokens_per_entry, n_categories, vocab, None, None, None)
+        return _finish_c5(tok, rng, entries, tokens_per_entry, n_categories, vocab, targets, plant_from, sources, lex)
+    return _finish_c5(tok, rng, entries, tokens_per_entry, n_categories, vocab, None, None, None, lex)
 
 
-def _finish_c5(tok, rng, entries, tokens_per_entry, n_categories, vocab, targets, plant_from, sources):
+def _finish_c5(tok, rng, entries, tokens_per_entry, n_categories, vocab, targets, plant_from, sources, lex=None):
     n, width = tok.shape
     cols = np.concatenate([np.arange(e * tokens_per_entry, (e + 1) * tokens_per_entry) for e in range(entries - 1, -1, -1)])
     nested = tok[:, cols]
@@ -188,15 +192,16 @@ def _finish_c5(tok, rng, entries, tokens_per_entry, n_categories, vocab, targets
     if targets is not None:  # planted items keep their source's categories (so the pair survives the filter)
         cat[targets] = plant_from["cat"][sources]
     return {"tok": tok, "ids": ids, "plen": plen, "nlev": np.full(n, entries, dtype=np.int32), "cat": cat,
-            "entries": entries, "tokens_per_entry": tokens_per_entry}
+            "entries": entries, "tokens_per_entry": tokens_per_entry, "lex": lex}
 
 
 def c5_level_token_lists(cohort: dict, rows: slice = slice(None)) -> List[List[List[str]]]:
     """``gen_comp_value`` output of the cohort's items: per item the level token lists."""
     tok, e, t = cohort["tok"][rows], cohort["entries"], cohort["tokens_per_entry"]
     out = []
+    lex = cohort.get("lex")
     for row in tok:
-        words = [f"t{int(v)}" for v in row]
+        words = [f"t{int(v)}" for v in row] if lex is None else [lex[int(v)] for v in row]
         out.append([sorted(set(words[(e - 1 - lv) * t:]), key=str.casefold) for lv in range(e)])
     return out
 
@@ -216,6 +221,25 @@ def term_vocabulary(vocab: int = 5000, seed: int = 99) -> List[str]:
     weight = 1.0 / np.arange(1, len(letters) + 1) ** 0.7
     weight /= weight.sum()
     return ["".join(rng.choice(letters, size=int(rng.integers(3, 13)), p=weight)) for _ in range(vocab)]
+
+
+WORD_ALPHABET = " " + _TERM_LETTERS  # code units of the c5w level strings, in code order (blank = 0)
+
+
+def word_vocabulary(vocab: int = 20_000, seed: int = 77, letters=(3, 7)) -> List[str]:
+    """``vocab`` DISTINCT German-looking words of ``letters[0]..letters[1]`` letters (the skewed letter distribution
+    of ``term_vocabulary``): eight of them joined with blanks stay within one 64-code-unit row."""
+    rng = np.random.default_rng(seed)
+    alpha = np.array(list(_TERM_LETTERS))
+    weight = 1.0 / np.arange(1, len(alpha) + 1) ** 0.7
+    weight /= weight.sum()
+    seen, out = set(), []
+    while len(out) < vocab:
+        w = "".join(rng.choice(alpha, size=int(rng.integers(letters[0], letters[1] + 1)), p=weight))
+        if w not in seen:
+            seen.add(w)
+            out.append(w)
+    return out
 
 
 def term_cohort(n: int, seed: int, vocab: int = 5000, entries=(3, 5), words=(2, 5), plant_from: list = None,
@@ -266,24 +290,36 @@ def term_levels(items: List[List[List[str]]]) -> List[List[List[str]]]:
 C5_ALPHABET = " t0123456789"  # code units of the C5 level strings, in code order
 
 
+def c5_alphabet(cohort: dict) -> str:
+    return C5_ALPHABET if cohort.get("lex") is None else WORD_ALPHABET
+
+
 def c5_level_codes(cohort: dict, vocab: int = 20_000):
     """The fuzzy_match operands of a C5 cohort as dense code units, vectorised: what
     ``[[fuzzy_operand(level) for level in item] for item in c5_level_token_lists(cohort)]`` followed by
     ``Alphabet.encode`` yields, without building 4 n Python strings (configs[4]: 6 million).
     Returns ``codes`` uint8 [n * entries][64] (level l of item k is row k * entries + l; unused slots 0),
-    ``lengths`` int32 [n * entries], ``first`` int32 [n], ``nlev`` int32 [n]; the alphabet is ``C5_ALPHABET``."""
+    ``lengths`` int32 [n * entries], ``first`` int32 [n], ``nlev`` int32 [n]; the alphabet is ``c5_alphabet(cohort)``
+    (``C5_ALPHABET`` for ``t<id>`` words, ``WORD_ALPHABET`` for a cohort with a lexicon)."""
     tok, e, t = cohort["tok"], cohort["entries"], cohort["tokens_per_entry"]
     n = tok.shape[0]
-    vocab = max(vocab, int(tok.max(initial=0)) + 1)
-    names = [f"t{v}" for v in range(vocab)]
-    order = sorted(range(vocab), key=lambda v: names[v])  # str order == casefold order for "t<digits>"
+    lex = cohort.get("lex")
+    if lex is None:
+        vocab = max(vocab, int(tok.max(initial=0)) + 1)
+        names = [f"t{v}" for v in range(vocab)]
+        alphabet = C5_ALPHABET
+    else:
+        names, vocab, alphabet = lex, len(lex), WORD_ALPHABET
+    code_of = {ch: k for k, ch in enumerate(alphabet)}
+    order = sorted(range(vocab), key=lambda v: names[v].casefold())  # (ties cannot occur: the words are distinct)
     rank = np.empty(vocab, dtype=np.int64)
     rank[order] = np.arange(vocab)
-    ndig = np.array([len(s) - 1 for s in names], dtype=np.int64)
-    digit = np.zeros((vocab, 5), dtype=np.uint8)
+    wlen = np.array([len(s) for s in names], dtype=np.int64)
+    wmax = int(wlen.max())
+    wcode = np.zeros((vocab, wmax), dtype=np.uint8)
     for v, s in enumerate(names):
-        digit[v, : len(s) - 1] = np.frombuffer(s[1:].encode(), dtype=np.uint8) - ord("0") + 2
-    if e * t * 7 - 1 > 64:
+        wcode[v, : len(s)] = [code_of[ch] for ch in s]
+    if e * t * (wmax + 1) - 1 > 64:
         raise NotImplementedError("level strings longer than one 64-code-unit row")
     codes = np.zeros((n * e, 64), dtype=np.uint8)
     lengths = np.zeros(n * e, dtype=np.int32)
@@ -293,15 +329,14 @@ def c5_level_codes(cohort: dict, vocab: int = 20_000):
         srt = np.take_along_axis(words, np.argsort(rank[words], axis=1, kind="stable"), axis=1)
         keep = np.ones(srt.shape, dtype=bool)
         keep[:, 1:] = srt[:, 1:] != srt[:, :-1]  # sorted(set(...))
-        span = np.where(keep, ndig[srt] + 2, 0)  # "t" + digits + the blank in front of the next word
+        span = np.where(keep, wlen[srt] + 1, 0)  # the word + the blank in front of the next word
         end = np.cumsum(span, axis=1)
         start = end - span
         rows = (item * e + lv)[:, None].repeat(srt.shape[1], axis=1)
         r, s, w = rows[keep], start[keep], srt[keep]
-        codes[r, s] = 1  # "t"
-        for d in range(5):
-            on = ndig[w] > d
-            codes[r[on], s[on] + 1 + d] = digit[w[on], d]
+        for d in range(wmax):
+            on = wlen[w] > d
+            codes[r[on], s[on] + d] = wcode[w[on], d]
         # (the blank between two words has code 0: already there)
         lengths[item * e + lv] = (end[:, -1] - 1).astype(np.int32)
     first = (np.arange(n, dtype=np.int32) * e).astype(np.int32)

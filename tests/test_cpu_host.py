@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     from napkon_string_matching_amd import _lib
 
     header = (ROOT / "include" / "nsm_hip.h").read_text()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(nsm_[a-z_]+)\s*\(", header, re.M))
+    declared = set(re.findall(r"^(?:int|uint64_t|const char\*)\s+(nsm_[a-z_]+)\s*\(", header, re.M))
     assert declared == set(_lib.EXPORTS)
     if not _lib.LIB_PATH.exists():
         pytest.skip("libnsm_hip.so not built (run __graft_entry__.build())")

@@ -419,12 +419,12 @@ def test_indel_levels_park_overflow(dev, thr):
 
 @pytest.mark.parametrize("extra", [0, 6])  # 6: level strings of 33..64 code units on both sides (the finish kernel's two-sweep LCS)
 @pytest.mark.parametrize("thr", [0.7, 0.8, 0.9])
-def test_indel_levels_split_path(dev, thr, extra, monkeypatch):
-    """One-word level strings at thresholds >= 0.7 take the split path (scan kernel -> global survivor queue -> finish
-    kernel).  It must give the hits of the fused park kernel (NSM_FLAG_PARK), of the wave-wide kernel and of the oracle --
-    also when the queue overflows (NSM_SPLIT_QUEUE_CAP forces it: the hit counter is put back and the gated fused kernel
-    redoes the grid), and when whole right tiles survive step 1 (the wave's LDS buffer is flushed in the middle of a
-    batch)."""
+def test_indel_levels_split_path(dev, thr, extra):
+    """One-word level strings at thresholds >= 0.7 take the split path (scan kernel -> survivor queue in the CALLER's
+    workspace -> finish kernel).  It must give the hits of the fused park kernel (NSM_FLAG_PARK), of the wave-wide kernel
+    and of the oracle -- also when the queue overflows (a workspace of a few hundred bytes forces it: the hit counter is
+    put back and the gated fused kernel redoes the grid), and when whole right tiles survive step 1 (the wave's LDS
+    buffer is flushed in the middle of a batch)."""
     from napkon_string_matching_amd import _lib, grid, tables
     from oracle import native
 
@@ -447,6 +447,7 @@ def test_indel_levels_split_path(dev, thr, extra, monkeypatch):
     lcat = np.array([rng.choice([1, 2, 3, 4, 6]) for _ in left], dtype=np.uint64)
     rcat = np.array([rng.choice([1, 2, 3, 5]) for _ in right], dtype=np.uint64)
     cps = lambda items: [[[ord(c) for c in s] for s in it] for it in items]
+    lib = _lib.load()
     for mode, partition in ((_lib.CAT_INTERSECT, True), (_lib.CAT_INTERSECT, False), (_lib.CAT_NONE, False)):
         li, ls, ri, rs = tables.encode_level_strings(left, right, dev, lcat, rcat, mode, partition=partition)
         assert ls.stride == 64
@@ -454,33 +455,94 @@ def test_indel_levels_split_path(dev, thr, extra, monkeypatch):
         assert len(want) > 50
         fused = grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, capacity=1 << 16, park=True)
         _same_hits(fused, want)
-        for cap in (None, "1", "100", "5000"):
-            if cap is None:
-                monkeypatch.delenv("NSM_SPLIT_QUEUE_CAP", raising=False)
-            else:
-                monkeypatch.setenv("NSM_SPLIT_QUEUE_CAP", cap)
-            split = grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, capacity=1 << 16)
-            assert split.as_tuples() == fused.as_tuples(), (mode, partition, cap)
-            small = grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, capacity=64)  # hit buffer grown once
+        asked = int(lib.nsm_indel_levels_workspace_bytes(li.struct(), ls.struct(), ri.struct(), rs.struct(), thr, _lib.FLAG_PRUNE))
+        assert asked > 512 + 16 * 65536  # the grid qualifies for the split path
+        assert lib.nsm_indel_levels_workspace_bytes(li.struct(), ls.struct(), ri.struct(), rs.struct(), 0.5, _lib.FLAG_PRUNE) == 0
+        assert lib.nsm_indel_levels_workspace_bytes(li.struct(), ls.struct(), ri.struct(), rs.struct(), thr,
+                                                    _lib.FLAG_PRUNE | _lib.FLAG_PARK) == 0
+        # None = what the library asks for; 0 = no workspace (single-kernel path); the small ones overflow (queue halves of
+        # 32, 100 and 5000 entries), 1024 bytes is the smallest workspace the library uses at all
+        for nbytes in (None, 0, 1024, 512 + 16 * 100, 512 + 16 * 5000):
+            flag = []
+            split = grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, capacity=1 << 16, workspace=nbytes,
+                                           return_overflow=flag)
+            assert split.as_tuples() == fused.as_tuples(), (mode, partition, nbytes)
+            if nbytes is None:
+                assert flag == [0]  # the recommended size never overflows here
+            elif nbytes == 1024:
+                assert flag == [1]  # 32 entries per half: overflow, the gated fused kernel redid the grid
+            small = grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, capacity=64, workspace=nbytes)  # hit buffer grown once
             assert small.as_tuples() == fused.as_tuples()
             # a hit buffer that already holds records: the overflow path puts the counter back to THEIR number
             buf = grid.HitBuffer(1 << 16, dev)
             buf.reset()
             buf.count.fill_(5)
-            lib = _lib.load()
             cm = li.category_mode if li.category_mode is not None else mode
+            ws = torch.empty(max(1, (nbytes if nbytes is not None else asked) // 8), dtype=torch.int64, device=dev)
             _lib.check(lib.nsm_indel_levels_grid(li.struct(), ls.struct(), ri.struct(), rs.struct(), thr, int(cm), _lib.FLAG_PRUNE,
-                                                 buf.records.data_ptr(), buf.capacity, buf.count.data_ptr(),
+                                                 buf.records.data_ptr(), buf.capacity, buf.count.data_ptr(), ws.data_ptr(),
+                                                 nbytes if nbytes is not None else asked,
                                                  torch.cuda.current_stream(dev).cuda_stream), "nsm_indel_levels_grid")
             assert int(buf.count.item()) == 5 + len(want)
-        monkeypatch.delenv("NSM_SPLIT_QUEUE_CAP", raising=False)
+    assert lib.nsm_release(torch.cuda.current_stream(dev).cuda_stream) == 0  # the side stream and events of this stream
+    again = grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, capacity=1 << 16)  # ... are re-created on demand
+    assert again.as_tuples() == fused.as_tuples()
+    assert lib.nsm_release_all() == 0
+
+
+@pytest.mark.parametrize("partition", [True, False])
+def test_indel_levels_split_path_many_rounds(dev, partition):
+    """The split path in SEVERAL rounds that do not overflow -- what every large grid runs (configs[4] at 500k rows: 3
+    rounds).  A workspace of a third of the expected survivors forces >= 3 rounds over the left slices (slice_base /
+    slices_total, both queue halves, the scanned / finished events re-used from round 2 on, scan and finish kernels
+    appending hits side by side); the overflow word must stay 0, so the gated fused kernel did NOT redo the grid and the
+    hits are the rounds' own.  (round-3 advice: the overflowing caps masked the rounds, the large ones ran a single round)"""
+    from napkon_string_matching_amd import _lib, grid, synthetic, tables
+    from oracle import native
+
+    hap = synthetic.c5_cohort(3000, 21)
+    pop = synthetic.c5_cohort(3500, 22, plant_from=hap, plant_fraction=0.05)
+    mode = _lib.CAT_INTERSECT_OR_BOTH_EMPTY if partition else _lib.CAT_NONE
+    li, ls, ri, rs = tables.encode_level_codes(synthetic.c5_level_codes(hap), synthetic.c5_level_codes(pop),
+                                               len(synthetic.C5_ALPHABET), dev, hap["cat"] if partition else None,
+                                               pop["cat"] if partition else None, mode)
+    assert (li.seg is not None) == partition
+    cps = lambda c: [[[ord(ch) for ch in " ".join(level)] for level in item] for item in synthetic.c5_level_token_lists(c)]
+    want = native.levels(True, cps(hap), cps(pop), 0.7, hap["cat"] if partition else None, pop["cat"] if partition else None,
+                         mode, cap=1 << 20)
+    assert len(want) > 100
+    fused = grid.indel_levels_grid(li, ls, ri, rs, 0.7, category_mode=mode, park=True)
+    _same_hits(fused, want)
+    # expected survivors (the library's estimate): 2 % of the pairs, 1/16 of that with a partition
+    expect = 3000 * 3500 * 0.02 * (1 / 16 if partition else 1.0)
+    seen_rounds = set()
+    for rounds_wanted in (3, 5, 8):
+        entries = int(expect / (rounds_wanted - 0.5))
+        nbytes = 512 + 16 * entries
+        ws = torch.full((nbytes // 8,), -1, dtype=torch.int64, device=dev)
+        buf = grid.HitBuffer(1 << 20, dev)
+        buf.reset()
+        lib = _lib.load()
+        cm = li.category_mode if li.category_mode is not None else mode
+        _lib.check(lib.nsm_indel_levels_grid(li.struct(), ls.struct(), ri.struct(), rs.struct(), 0.7, int(cm), _lib.FLAG_PRUNE,
+                                             buf.records.data_ptr(), buf.capacity, buf.count.data_ptr(), ws.data_ptr(), nbytes,
+                                             torch.cuda.current_stream(dev).cuda_stream), "nsm_indel_levels_grid")
+        n = int(buf.count.item())
+        ctl = ws[:64].cpu().numpy()
+        assert int(ctl[1]) & 0xFFFFFFFF == 0, "the queue overflowed: the rounds were not what produced the hits"
+        per_round = [int(v) for v in ctl[2:64] if v > 0]
+        assert len(per_round) >= rounds_wanted - 1 and max(per_round) <= entries, (per_round, entries)
+        seen_rounds.add(len(per_round))
+        got = grid.sort_hits_device(buf, n)
+        assert got.as_tuples() == fused.as_tuples(), (partition, rounds_wanted)
+    assert max(seen_rounds) >= 5
 
 
 def test_indel_levels_split_path_under_graph_capture(dev):
-    """The split path keeps a device workspace per (device, stream) and runs its finish kernels on a stream of its own.
-    Captured into a hipGraph it must neither allocate nor lose work: on a stream whose workspace an eager call has sized
-    the capture records the split path (fork / join through the library's events), on a stream that never ran it the call
-    falls back to the single-kernel path; both replays give the eager call's hits."""
+    """The split path's queue lives in the caller's workspace; its finish kernels run on a library-owned side stream
+    in eager mode.  Captured into a hipGraph the call stays on the capturing stream alone (no stream or event is created
+    under capture): the replay must give the eager call's hits, with a workspace (split path, one stream) and without
+    (single-kernel path)."""
     from napkon_string_matching_amd import _lib, grid, tables
 
     rng = random.Random(515)
@@ -498,34 +560,41 @@ def test_indel_levels_split_path_under_graph_capture(dev):
     want = grid.indel_levels_grid(li, ls, ri, rs, 0.7, park=True).as_tuples()
     assert len(want) > 100
     lib = _lib.load()
-
-    def launch(buf, stream):
-        buf.count.zero_()
-        _lib.check(lib.nsm_indel_levels_grid(li.struct(), ls.struct(), ri.struct(), rs.struct(), 0.7, _lib.CAT_NONE, _lib.FLAG_PRUNE,
-                                             buf.records.data_ptr(), buf.capacity, buf.count.data_ptr(), stream.cuda_stream),
-                   "nsm_indel_levels_grid")
+    asked = int(lib.nsm_indel_levels_workspace_bytes(li.struct(), ls.struct(), ri.struct(), rs.struct(), 0.7, _lib.FLAG_PRUNE))
+    assert asked > 0
 
     def hits_of(buf):
         n = int(buf.count.item())
         rec = grid.sort_hits_device(buf, n)
         return rec.as_tuples()
 
-    for warm in (True, False):
+    for with_ws in (True, False):
+        ws = torch.empty(asked // 8, dtype=torch.int64, device=dev) if with_ws else None
+
+        def launch(buf, stream):
+            buf.count.zero_()
+            _lib.check(lib.nsm_indel_levels_grid(li.struct(), ls.struct(), ri.struct(), rs.struct(), 0.7, _lib.CAT_NONE,
+                                                 _lib.FLAG_PRUNE, buf.records.data_ptr(), buf.capacity, buf.count.data_ptr(),
+                                                 ws.data_ptr() if ws is not None else 0, asked if ws is not None else 0,
+                                                 stream.cuda_stream), "nsm_indel_levels_grid")
+
         stream = torch.cuda.Stream(dev)
         buf = grid.HitBuffer(1 << 14, dev)
         buf.reset()
         with torch.cuda.stream(stream):
-            if warm:
-                launch(buf, stream)  # sizes this stream's workspace
-                stream.synchronize()
-                assert hits_of(buf) == want
+            launch(buf, stream)  # eager (with a workspace: the side stream of this stream is created here)
+            stream.synchronize()
+            assert hits_of(buf) == want
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=stream):
                 launch(buf, stream)
             for _ in range(2):
                 g.replay()
                 torch.cuda.synchronize(dev)
-                assert hits_of(buf) == want, warm
+                assert hits_of(buf) == want, with_ws
+            if ws is not None:
+                assert int(ws[1].item()) & 0xFFFFFFFF == 0
+        lib.nsm_release(stream.cuda_stream)
 
 
 @pytest.mark.parametrize("hi", [90, 230, 480])

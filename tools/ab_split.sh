@@ -25,6 +25,5 @@ lev "split 0.8" - 0.8 1
 lev "fused 0.8" - 0.8 17
 unset NSM_HIP_LIBRARY
 bash tools/ab_c5.sh - $V/libnsm_w5.so
-NSM_SPLIT_QUEUE_CAP=33554432 bash tools/ab_c5.sh -
-NSM_SPLIT_QUEUE_CAP=536870912 bash tools/ab_c5.sh -
+# (round 4: the queue is the caller's workspace -- python3 bench.py --workload c5 --split-workspace-mb 512 | 8192)
 } 2>&1 | tee $out/ab.txt

@@ -77,15 +77,20 @@ def main():
         _lib.check(lib.nsm_jaccard_levels_grid(set_tables[a, "left"].struct(), set_tables[b, "right"].struct(),
                                                args.threshold, set_tables[a, "left"].category_mode, args.jaccard_flags, buf.records.data_ptr(), buf.capacity,
                                                buf.count.data_ptr(), stream), "jaccard_levels")
-        lib.nsm_sort_hits(buf.records.data_ptr(), buf.scratch.data_ptr(), buf.capacity, buf.count.data_ptr(), stream)
+        lib.nsm_sort_hits(buf.records.data_ptr(), buf.scratch.data_ptr(), buf.capacity, buf.count.data_ptr(), 0, args.rows, stream)
+
+    ws_bytes = max(int(lib.nsm_indel_levels_workspace_bytes(t[0].struct(), t[1].struct(), t[2].struct(), t[3].struct(),
+                                                            args.threshold, args.indel_flags)) for t in str_tables.values())
+    ws = grid.split_workspace(ws_bytes, dev) if ws_bytes else None  # the split path's survivor queue: caller-owned (ABI 4)
 
     def run_indel(a, b):
         li, ls, ri, rs = str_tables[a, b]
         buf.count.zero_()
         _lib.check(lib.nsm_indel_levels_grid(li.struct(), ls.struct(), ri.struct(), rs.struct(), args.threshold,
                                              li.category_mode, args.indel_flags, buf.records.data_ptr(), buf.capacity, buf.count.data_ptr(),
+                                             ws.data_ptr() if ws is not None else 0, ws.numel() * 8 if ws is not None else 0,
                                              stream), "indel_levels")
-        lib.nsm_sort_hits(buf.records.data_ptr(), buf.scratch.data_ptr(), buf.capacity, buf.count.data_ptr(), stream)
+        lib.nsm_sort_hits(buf.records.data_ptr(), buf.scratch.data_ptr(), buf.capacity, buf.count.data_ptr(), 0, args.rows, stream)
 
     out = {"rows_per_cohort": args.rows, "threshold": args.threshold, "pairs_per_grid": args.rows ** 2,
            "tokens_per_entry": args.tokens_per_entry, "string_stride": str_tables[pairs[0]][1].stride,

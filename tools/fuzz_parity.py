@@ -200,7 +200,7 @@ def main():
                     # sometimes with a queue so small that it overflows (gated fused fallback)
                     hi = rng.choice([12, 30, 40, 64])
                     thr = rng.choice([0.7, 0.7, 0.75, 0.8, 0.9, 1.0])
-                    queue_cap = rng.choice([None, None, "1", "64", "2000"])
+                    queue_cap = rng.choice([None, None, 1024, 512 + 16 * 64, 512 + 16 * 2000])  # workspace bytes
                 alphabet = rng.choice(["abc ", "abcdefghij klm", "abcdefghijklmnopqrstuvwxyz0123456789 "])
                 max_levels = rng.choice([1, 2, 4, 4, 7])
                 item = lambda: [rand_string(rng, alphabet, 0, hi) for _ in range(rng.randint(1, max_levels))]
@@ -220,14 +220,9 @@ def main():
                 # (one-word strings: the split path at thresholds >= 0.7, else -- and with park -- the fused park kernel)
                 park = rng.random() < 0.25 and family != "indel_split"
                 prune = rng.random() < 0.8 or family == "indel_split"
-                if queue_cap is None:
-                    os.environ.pop("NSM_SPLIT_QUEUE_CAP", None)
-                else:
-                    os.environ["NSM_SPLIT_QUEUE_CAP"] = queue_cap
-                check(grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, park=park, prune=prune), want,
+                check(grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, park=park, prune=prune, workspace=queue_cap), want,
                       f"{family} hi={hi} |alphabet|={len(alphabet)} levels<={max_levels} thr={thr} mode={mode} "
                       f"partition={partition} ncat={ncat} park={park} prune={prune} stride={ls.stride} queue_cap={queue_cap} {n}x{m}")
-                os.environ.pop("NSM_SPLIT_QUEUE_CAP", None)
     print(json.dumps({"ok": True, "rounds": counts, "oracle_hits_compared": total_hits, "seconds": args.seconds,
                       "first_seed": args.seed + 1, "last_seed": rnd}))
 

@@ -15,6 +15,7 @@ for w in $loads; do
   case $w in
     levels) cmd="python3 tools/bench_levels.py --rows 100000 --steps 2";;
     c5) cmd="python3 bench.py --workload c5 --steps 1 --warmup 1 --no-cpu-baseline";;
+    c5w) cmd="python3 bench.py --workload c5w --steps 1 --warmup 1 --no-cpu-baseline --no-extras";;
     c4) cmd="python3 bench.py --workload c4 --steps 2 --warmup 1 --no-cpu-baseline";;
     *) cmd="python3 bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline";;
   esac

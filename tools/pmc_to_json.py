@@ -34,7 +34,7 @@ def csrc_hash() -> str:
 
 
 def short(name: str) -> str:
-    name = name.replace("void ", "")
+    name = name.replace("void ", "").replace("(anonymous namespace)::", "")  # (else every such kernel collapses to "nsm::")
     return name.split("(")[0].strip()
 
 
