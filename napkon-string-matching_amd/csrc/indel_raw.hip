@@ -67,8 +67,11 @@ __device__ __forceinline__ unsigned long long add64(unsigned long long a, unsign
   return d;
 }
 
+#ifndef NSM_C3_OCC
+#define NSM_C3_OCC
+#endif
 template <bool PRUNE>
-__global__ __launch_bounds__(kBlock) void indel_raw_kernel(
+__global__ __launch_bounds__(kBlock) NSM_C3_OCC void indel_raw_kernel(
     const uint8_t* __restrict__ lcodes, const int32_t* __restrict__ llen, const int32_t* __restrict__ lstart,
     const int32_t* __restrict__ lorig, const uint32_t* __restrict__ lhist, const uint8_t* __restrict__ rcodes,
     const int32_t* __restrict__ rlen, const int32_t* __restrict__ rorig, const uint32_t* __restrict__ rhist,
@@ -99,21 +102,28 @@ __global__ __launch_bounds__(kBlock) void indel_raw_kernel(
   // therefore stored in BOTH halves of its entry and symbol c is read from half (c >> 4) & 1: symbols 0..31
   // map to 32 different banks.  The half is baked into the text's addresses, which are rebuilt when the
   // pattern class changes between wide and narrow (rows are sorted by length: once per chunk).
-  uint32_t taddr[32];
+  // PRUNE = false (every row runs the LCS): the text is unpacked once into 32 registers, below.  PRUNE = true: LCS rows
+  // are rare (< 0.1 % of the rows a wave visits on C3), so the text is re-read 16 code units at a time on such a row
+  // and no register outlives it -- the histogram loop is what runs, and it runs at the occupancy its OWN registers allow
+  // (round 4: the 32 address registers of the rare LCS path had put the whole kernel at 88 VGPRs = 5 waves per SIMD, with
+  // 65 % of the wave-cycles spent waiting for the scalar loads of the histogram loop; <= 64 VGPRs = 8 waves).
+  uint32_t taddr[PRUNE ? 1 : 32];
   auto build_taddr = [&](bool narrow) {
-    const uint4* tp = reinterpret_cast<const uint4*>(rcodes + static_cast<size_t>(jc) * 64);
-    const uint32_t hsel = narrow ? 4u : 0u;
+    if constexpr (!PRUNE) {
+      const uint4* tp = reinterpret_cast<const uint4*>(rcodes + static_cast<size_t>(jc) * 64);
+      const uint32_t hsel = narrow ? 4u : 0u;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const uint4 v = tp[q];
-      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+      for (int q = 0; q < 4; ++q) {
+        const uint4 v = tp[q];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const uint32_t c0 = w[e] & 0xffu, c1 = (w[e] >> 8) & 0xffu, c2 = (w[e] >> 16) & 0xffu, c3 = w[e] >> 24;
-        const uint32_t a0 = pm_base + 8 * c0 + (((c0 >> 4) & 1u) ? hsel : 0u), a1 = pm_base + 8 * c1 + (((c1 >> 4) & 1u) ? hsel : 0u);
-        const uint32_t a2 = pm_base + 8 * c2 + (((c2 >> 4) & 1u) ? hsel : 0u), a3 = pm_base + 8 * c3 + (((c3 >> 4) & 1u) ? hsel : 0u);
-        taddr[8 * q + 2 * e + 0] = a0 | (a1 << 16);
-        taddr[8 * q + 2 * e + 1] = a2 | (a3 << 16);
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t c0 = w[e] & 0xffu, c1 = (w[e] >> 8) & 0xffu, c2 = (w[e] >> 16) & 0xffu, c3 = w[e] >> 24;
+          const uint32_t a0 = pm_base + 8 * c0 + (((c0 >> 4) & 1u) ? hsel : 0u), a1 = pm_base + 8 * c1 + (((c1 >> 4) & 1u) ? hsel : 0u);
+          const uint32_t a2 = pm_base + 8 * c2 + (((c2 >> 4) & 1u) ? hsel : 0u), a3 = pm_base + 8 * c3 + (((c3 >> 4) & 1u) ? hsel : 0u);
+          taddr[8 * q + 2 * e + 0] = a0 | (a1 << 16);
+          taddr[8 * q + 2 * e + 1] = a2 | (a3 << 16);
+        }
       }
     }
   };
@@ -134,12 +144,8 @@ __global__ __launch_bounds__(kBlock) void indel_raw_kernel(
   const int i0 = blockIdx.y * p.rows_per_chunk;
   const int i1 = min(p.n_left, i0 + p.rows_per_chunk);
 
-  // ---- LCS of pattern row i (length la, match masks built here) against the lane's text
-  auto lcs_row = [&](int i, int la, bool wide) -> int {
-    if (PRUNE || taddr_narrow != static_cast<int>(!wide)) {
-      build_taddr(!wide);
-      taddr_narrow = static_cast<int>(!wide);
-    }
+  // the wave's match-mask table of pattern row i: one ds_write_b64 sweep to clear, one ds_or_b64 to set
+  auto build_masks = [&](int i, int la, bool wide) {
     for (int c = lane; c < p.pm_stride; c += kWave) pm[c] = 0ull;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -149,6 +155,52 @@ __global__ __launch_bounds__(kBlock) void indel_raw_kernel(
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+  };
+
+  // ---- LCS of pattern row i (length la, match masks built here) against the lane's text
+  auto lcs_row = [&](int i, int la, bool wide) -> int {
+    if constexpr (PRUNE) {
+      // lean form: 16 code units of the text per global load, addresses computed on the fly
+      build_masks(i, la, wide);
+      const uint4* tp = reinterpret_cast<const uint4*>(rcodes + static_cast<size_t>(jc) * 64);
+      const uint32_t hsel = wide ? 0u : 4u;
+      const int nchars = 2 * npairs;
+      uint32_t v32 = ~0u;
+      unsigned long long v64 = ~0ull;
+      for (int q = 0; q < 4; ++q) {
+        if (q * 16 >= nchars) break;
+        const uint4 t4 = tp[q];
+        const uint32_t w[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          uint32_t addr[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const uint32_t c = (w[e] >> (8 * k)) & 0xffu;
+            addr[k] = pm_base + 8 * c + (((c >> 4) & 1u) ? hsel : 0u);
+          }
+          if (!wide) {
+            uint32_t m[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m[k] = lds_load<uint32_t>(addr[k]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v32 = lcs_step32(v32, m[k]);
+          } else {
+            unsigned long long m[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m[k] = lds_load<unsigned long long>(addr[k]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v64 = lcs_step64(v64, m[k]);
+          }
+        }
+      }
+      return wide ? 64 - __popcll(v64) : 32 - __popc(v32);
+    }
+    if (taddr_narrow != static_cast<int>(!wide)) {
+      build_taddr(!wide);
+      taddr_narrow = static_cast<int>(!wide);
+    }
+    build_masks(i, la, wide);
     // 8 code units per group: their mask reads are issued together (one LDS round trip per group instead of one
     // per dependent step), the recurrence is spelled as e32 instructions (nsm_common.hpp: lcs_step32 / 64)
     const int nchars = 2 * npairs;
@@ -160,8 +212,8 @@ __global__ __launch_bounds__(kBlock) void indel_raw_kernel(
           uint32_t m[8];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            m[2 * q] = lds_load<uint32_t>(taddr[4 * g + q] & lowmask);
-            m[2 * q + 1] = lds_load<uint32_t>(taddr[4 * g + q] >> 16);
+            m[2 * q] = lds_load<uint32_t>(taddr[(4 * g + q) % (PRUNE ? 1 : 32)] & lowmask);
+            m[2 * q + 1] = lds_load<uint32_t>(taddr[(4 * g + q) % (PRUNE ? 1 : 32)] >> 16);
           }
 #pragma unroll
           for (int q = 0; q < 8; ++q) v = lcs_step32(v, m[q]);
@@ -176,8 +228,8 @@ __global__ __launch_bounds__(kBlock) void indel_raw_kernel(
         unsigned long long m[8];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          m[2 * q] = lds_load<unsigned long long>(taddr[4 * g + q] & lowmask);
-          m[2 * q + 1] = lds_load<unsigned long long>(taddr[4 * g + q] >> 16);
+          m[2 * q] = lds_load<unsigned long long>(taddr[(4 * g + q) % (PRUNE ? 1 : 32)] & lowmask);
+          m[2 * q + 1] = lds_load<unsigned long long>(taddr[(4 * g + q) % (PRUNE ? 1 : 32)] >> 16);
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) v = lcs_step64(v, m[q]);
@@ -218,10 +270,16 @@ __global__ __launch_bounds__(kBlock) void indel_raw_kernel(
       // exactly when L1 <= limit; one full-rate v_or per row folds the signs into the batch's verdict
       // (the scalar unit is shared by the CU's 4 SIMDs, keep it idle; v_cmp + v_addc per row cost
       // two half-rate ops).
-      constexpr int BATCH = 4;
       const uint32_t seed = static_cast<uint32_t>(-(limit + 1));
       const uint32_t* __restrict__ hp = lhist + static_cast<size_t>(a) * 8;
       int i = a;
+      // (Tried on top, same box, kernel ms against 6.52: a software pipeline over two scalar register sets of 2 rows each --
+      // the compiler needs 78 VGPRs for it, 6 waves per SIMD: 8.36; the same capped at 7 waves with 480 B of scratch: 7.86;
+      // 2 rows per batch, 73 SGPRs: 6.45.  At 8 waves per SIMD the other waves hide the scalar loads.)
+#ifndef NSM_C3_BATCH
+#define NSM_C3_BATCH 4
+#endif
+      constexpr int BATCH = NSM_C3_BATCH;
       for (; i + BATCH <= b; i += BATCH, hp += 8 * BATCH) {
         uint32_t h[8 * BATCH];
 #pragma unroll
@@ -268,7 +326,10 @@ static int pick_rows_per_chunk(int n_left, int n_tiles) {
   if (chunks < 1) chunks = 1;
   long long rows = (n_left + chunks - 1) / chunks;
   if (rows < 64) rows = 64;
-  if (rows > 4096) rows = 4096;
+#ifndef NSM_C3_CHUNK_MAX
+#define NSM_C3_CHUNK_MAX 4096
+#endif
+  if (rows > NSM_C3_CHUNK_MAX) rows = NSM_C3_CHUNK_MAX;
   return static_cast<int>(rows);
 }
 
