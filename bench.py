@@ -156,10 +156,10 @@ class Workload:
             torch.cuda.synchronize(device)
             self.encode_h2d_seconds = time.perf_counter() - t_enc
             self.launch_fn = self.lib.nsm_jaccard_raw_grid
-            self.kernel = "jaccard_raw_kernel<16>"
-            self.kernel_match, self.kernel_match_exhaustive = "jaccard_raw_kernel<16, true>", "jaccard_raw_kernel<16, false>"
-            if name == "c2low":  # low thresholds: candidates from the per-tile inverted index
-                self.kernel = self.kernel_match = "jaccard_raw_index_kernel<16>"
+            # the right table carries a global inverted index (tables.SetTable.from_padded): on these vocabularies the
+            # library generates candidates from it at every threshold (csrc/jaccard_raw_global.hip)
+            self.kernel = self.kernel_match = "jaccard_raw_global_kernel<16>"
+            self.kernel_match_exhaustive = "jaccard_raw_kernel<16, false>"
             self.dtype = "int32"
             self.label = (f"{name.upper()}: {n}x{m} token-id sets/GPU (Poisson(8) ids, W=16), intersection_vs_union RAW, "
                           f"threshold {self.threshold}")

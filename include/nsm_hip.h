@@ -57,7 +57,9 @@ typedef struct nsm_hit {
 } nsm_hit;
 
 /* Token-id set table of one side, rows sorted by `cnt` DESCENDING (the encoder does this).
- *   ids   device int32 [n][width]  unique ids >= 0, unused slots padded (left: -1, right: -2)
+ *   ids   device int32 [n][width]  unique ids >= 0, unused slots padded (left: -1, right: -2).  RAW tables: ascending
+ *                                  within the row (the builder sorts them; the global inverted index relies on it).
+ *                                  Levels tables: first-appearance order, see plen
  *   cnt   device int32 [n]         number of ids in the row (RAW) / in the item's largest level
  *   sig   device uint64[n]         signature word: bits 0..57 = OR over the row's ids of
  *                                  1 << ((((id * 0x9E3779B1u) >> 16) & 0xffff) * 58 >> 16); bits 58..63 =
@@ -82,6 +84,18 @@ typedef struct nsm_hit {
  *                                  is the signature word (same layout as sig) of the row's first
  *                                  plen[min(1,L-1)] ids, i.e. of the set every step of compare_terms contains
  *                                  (one s_load per 2 rows)
+ *   -- global inverted index (RAW mode, optional: NULL = none).  nsm_build_set_table fills both columns when the caller
+ *      provides them; nsm_jaccard_raw_grid uses the RIGHT table's index to generate candidate pairs instead of visiting
+ *      all N x M (prefix filter: with the ids of every row in one global order -- ascending id -- two sets can only reach
+ *      the threshold if they share an id among their first few; a host that numbers its tokens by INCREASING corpus
+ *      frequency gets the shortest posting lists, any numbering is correct) --
+ *   post        device uint64[n * width]    one entry per (row, id) sorted by (id, position p of the id in its row);
+ *                                           entry = row | p << 32 | cnt << 40; the unused tail is zero
+ *   post_start  device int32 [5 * vocab + 1] entries of id t with p < 1 / 2 / 4 / 8 / any are
+ *                                           [post_start[5 t], post_start[5 t + 1 / 2 / 3 / 4 / 5])
+ *   vocab       every id of the table is < vocab (checked by the builder)
+ *   post_sq     HOST values written by the builder: post_sq[c] = sum over ids of (number of its entries in
+ *               [post_start[5 t], post_start[5 t + c + 1]))^2 -- what the grid estimates its candidate count from
  */
 typedef struct nsm_set_table {
   const int32_t* ids;
@@ -99,6 +113,10 @@ typedef struct nsm_set_table {
   int32_t n;
   int32_t width;      /* 16, 32 or 64 */
   int32_t max_levels; /* row stride of plen */
+  int32_t vocab;      /* ids are < vocab (only read when post / post_start are given) */
+  const uint64_t* post;
+  const int32_t* post_start;
+  uint64_t post_sq[5];
 } nsm_set_table;
 
 /* Code-unit string table of one side, rows sorted by `len` DESCENDING.
@@ -153,8 +171,11 @@ typedef struct nsm_level_items {
 
 #define NSM_FLAG_PRUNE 1u /* exact signature / length bound before the full comparison */
 #define NSM_FLAG_INDEX 4u    /* nsm_jaccard_raw_grid, nsm_jaccard_levels_grid: candidate generation by inverted index (chosen by
-                                itself at low thresholds, where the signature filter stops paying; this forces it) */
-#define NSM_FLAG_NO_INDEX 8u /* the same grids: never use the inverted index (A/B runs, tests) */
+                                itself where it pays; this forces it: the right table's global index when it has one, else
+                                the per-tile index built in LDS) */
+#define NSM_FLAG_NO_INDEX 8u /* the same grids: never use an inverted index (A/B runs, tests) */
+#define NSM_FLAG_TILE_INDEX 64u /* nsm_jaccard_raw_grid: with NSM_FLAG_INDEX, the per-tile LDS index even when the right table
+                                   carries a global one (A/B runs, tests) */
 #define NSM_FLAG_PARK 16u /* nsm_indel_levels_grid: the round-2 kernel alone (one right tile per wavefront, block-shared
                              park, dense finish inside the kernel) -- instead of the shared-tile kernel for strings beyond 64
                              code units, and instead of the split path (scan kernel -> survivor queue -> finish kernel) that

@@ -30,6 +30,7 @@ enum BuildError : int {
   kErrBadCode = 3,       // code unit above the alphabet / length outside [0, stride]
   kErrBit63 = 4,         // category bit 63 in use: the empty items cannot become a category of their own
   kErrBadLevels = 5,     // nlev outside [1, max_levels] / plen not non-decreasing or above cnt
+  kErrBadVocab = 6,      // an id >= the table's vocab (global inverted index)
 };
 
 struct Status {
@@ -210,6 +211,19 @@ __global__ void set_rows_kernel(const int32_t* __restrict__ ids_in, int n, int w
     atomicMax(&st->err, static_cast<int>(kErrRowTooWide));
     cnt = width;
   }
+  if (!nlev_in) {
+    // RAW rows: ids ascending (include/nsm_hip.h) -- ascending id is the global token order of the inverted index, and the
+    // prefix of a row in that order is its first few slots.  Insertion sort: rows hold <= 64 ids.
+    for (int a = 1; a < cnt; ++a) {
+      const int32_t v = dst[a];
+      int b = a - 1;
+      while (b >= 0 && dst[b] > v) {
+        dst[b + 1] = dst[b];
+        --b;
+      }
+      dst[b + 1] = v;
+    }
+  }
   if (nlev_in) {
     const int L = nlev_in[i];
     if (L < 1 || L > max_levels) atomicMax(&st->err, static_cast<int>(kErrBadLevels));
@@ -268,6 +282,65 @@ __global__ void set_gather_kernel(const int32_t* __restrict__ perm, const int32_
     f[6] = static_cast<uint32_t>(sl1 >> 32);
     f[7] = 0u;
   }
+}
+
+// ---------------------------------------------------------------------------------------------------- global inverted index
+// (RAW tables; include/nsm_hip.h: post / post_start).  One (key, entry) pair per table slot, key = id << 8 | position
+// (unused slots: all ones, sorted last), one radix sort, then the offsets: 5 boundaries per id (positions < 1, 2, 4, 8, any).
+__device__ __forceinline__ int post_class(int pos) { return pos < 1 ? 0 : pos < 2 ? 1 : pos < 4 ? 2 : pos < 8 ? 3 : 4; }
+
+__global__ void post_keys_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ cnt, int rows, int width, int vocab,
+                                 unsigned long long* __restrict__ keys, unsigned long long* __restrict__ vals, Status* st) {
+  const long long s = static_cast<long long>(blockIdx.x) * kThreads + threadIdx.x;
+  if (s >= static_cast<long long>(rows) * width) return;
+  const int r = static_cast<int>(s / width), k = static_cast<int>(s % width);
+  const int c = cnt[r];
+  unsigned long long key = ~0ull, val = 0ull;
+  if (k < c) {
+    const int32_t id = ids[s];
+    if (id >= vocab) atomicMax(&st->err, static_cast<int>(kErrBadVocab));
+    else {
+      key = (static_cast<unsigned long long>(static_cast<uint32_t>(id)) << 8) | static_cast<unsigned long long>(k);
+      val = static_cast<unsigned long long>(static_cast<uint32_t>(r)) | (static_cast<unsigned long long>(k) << 32) |
+            (static_cast<unsigned long long>(c) << 40);
+    }
+  }
+  keys[s] = key;
+  vals[s] = val;
+}
+
+// post_start[q] = index of the first sorted entry whose (id * 5 + class) is >= q, for q in [0, 5 vocab]
+__global__ void post_bounds_kernel(const unsigned long long* __restrict__ keys, long long n, int vocab, unsigned long long key_mask,
+                                   int32_t* __restrict__ post_start, unsigned long long* __restrict__ vals) {
+  const long long e = static_cast<long long>(blockIdx.x) * kThreads + threadIdx.x;
+  if (e > n) return;
+  const long long sentinel = 5ll * vocab;
+  auto ckey = [&](long long at) -> long long {
+    if (at < 0) return -1;
+    if (at >= n) return sentinel;
+    const unsigned long long k = keys[at];
+    if ((k & key_mask) == key_mask) return sentinel;  // an unused slot (all ones in the sorted bits)
+    return static_cast<long long>(k >> 8) * 5 + post_class(static_cast<int>(k & 0xffu));
+  };
+  const long long cur = ckey(e), prev = ckey(e - 1);
+  for (long long q = prev + 1; q <= cur; ++q) post_start[q] = static_cast<int32_t>(e);
+  if (e < n && cur == sentinel) vals[e] = 0ull;  // (the tail stays zero whatever the sort left there)
+}
+
+__global__ void post_stats_kernel(const int32_t* __restrict__ post_start, int vocab, unsigned long long* __restrict__ sq) {
+  __shared__ unsigned long long s_sq[5];
+  if (threadIdx.x < 5) s_sq[threadIdx.x] = 0ull;
+  __syncthreads();
+  const int t = blockIdx.x * kThreads + threadIdx.x;
+  if (t < vocab) {
+    const long long base = post_start[5ll * t];
+    for (int c = 0; c < 5; ++c) {
+      const unsigned long long len = static_cast<unsigned long long>(post_start[5ll * t + c + 1] - base);
+      if (len) atomicAdd(&s_sq[c], len * len);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 5 && s_sq[threadIdx.x]) atomicAdd(&sq[threadIdx.x], s_sq[threadIdx.x]);
 }
 
 // ---------------------------------------------------------------------------------------------------- string tables
@@ -372,6 +445,7 @@ const char* error_text(int err) {
     case kErrBit63: return "category bit 63 is in use: the empty items cannot become a category of their own "
                            "(encode both sides without a partition)";
     case kErrBadLevels: return "nlev outside its range, or plen not a non-decreasing prefix-length row";
+    case kErrBadVocab: return "an id is >= the table's vocab (the global inverted index addresses its offsets by id)";
     default: return "unknown";
   }
 }
@@ -508,7 +582,52 @@ extern "C" int nsm_build_set_table(const int32_t* ids_in, int32_t n, int32_t wid
     if (rows > 0) hipLaunchKernelGGL(widen_kernel, blocks_for(rows), dim3(kThreads), 0, stream, out->seg, rows, seg_class);
     if (int rc = class_starts(seg_class, rows, 64, const_cast<int32_t*>(out->seg_start), sc)) return rc;
   }
+  // global inverted index (RAW tables whose caller provides the two columns)
+  unsigned long long* d_sq = nullptr;
+  for (int c = 0; c < 5; ++c) out->post_sq[c] = 0;
+  if (out->post || out->post_start) {
+    if (levels || !out->post || !out->post_start || out->vocab < 1 || out->vocab > (1 << 25)) {
+      set_error("%s: the global inverted index needs a RAW table, both the post and post_start columns and vocab in [1, 2^25]", who);
+      return NSM_E_BADARG;
+    }
+    const long long slots = static_cast<long long>(rows) * width;
+    unsigned long long* keys = sc.get<unsigned long long>(slots);
+    unsigned long long* keys_sorted = sc.get<unsigned long long>(slots);
+    unsigned long long* vals = sc.get<unsigned long long>(slots);
+    d_sq = sc.get<unsigned long long>(5);
+    if (sc.failed) return hip_status(hipErrorOutOfMemory, "builder scratch");
+    (void)hipMemsetAsync(d_sq, 0, 5 * sizeof(unsigned long long), stream);
+    int bits = 1;
+    while ((1ll << bits) < out->vocab) ++bits;
+    bits += 8;
+    const unsigned long long key_mask = (1ull << bits) - 1ull;
+    unsigned long long* post = const_cast<unsigned long long*>(reinterpret_cast<const unsigned long long*>(out->post));
+    if (slots > 0) {
+      hipLaunchKernelGGL(post_keys_kernel, blocks_for(slots), dim3(kThreads), 0, stream, out->ids, out->cnt, rows, width, out->vocab,
+                         keys, vals, d_status);
+      size_t bytes = 0;
+      hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, keys, keys_sorted, vals, post, static_cast<size_t>(slots), 0u,
+                                               static_cast<unsigned>(bits), stream);
+      if (e != hipSuccess) return hip_status(e, "radix_sort_pairs (postings, size)");
+      char* temp = sc.get<char>(bytes);
+      if (sc.failed) return hip_status(hipErrorOutOfMemory, "builder scratch");
+      e = rocprim::radix_sort_pairs(temp, bytes, keys, keys_sorted, vals, post, static_cast<size_t>(slots), 0u,
+                                    static_cast<unsigned>(bits), stream);
+      if (e != hipSuccess) return hip_status(e, "radix_sort_pairs (postings)");
+    }
+    hipLaunchKernelGGL(post_bounds_kernel, blocks_for(slots + 1), dim3(kThreads), 0, stream, keys_sorted, slots, out->vocab, key_mask,
+                       const_cast<int32_t*>(out->post_start), post);
+    hipLaunchKernelGGL(post_stats_kernel, blocks_for(out->vocab), dim3(kThreads), 0, stream, out->post_start, out->vocab, d_sq);
+  }
   out->n = rows;
+  if (d_sq) {
+    unsigned long long h_sq[5] = {0, 0, 0, 0, 0};
+    if (hipMemcpyAsync(h_sq, d_sq, sizeof(h_sq), hipMemcpyDeviceToHost, stream) != hipSuccess)
+      return hip_status(hipGetLastError(), who);
+    const int rc = finish(d_status, stream, who, nullptr);  // (synchronises: h_sq has arrived)
+    for (int c = 0; c < 5; ++c) out->post_sq[c] = h_sq[c];
+    return rc;
+  }
   return finish(d_status, stream, who, nullptr);
 }
 

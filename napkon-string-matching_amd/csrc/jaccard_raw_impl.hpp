@@ -54,6 +54,12 @@ template <int W>
 int launch_raw_index(const nsm_set_table* l, const nsm_set_table* r, double threshold, nsm_hit* hits, uint64_t capacity,
                      unsigned long long* hit_count, hipStream_t stream);
 
+// Candidate generation from the right table's GLOBAL inverted index (jaccard_raw_global.hip).  `probe_only`: nothing is
+// launched, *estimate receives the number of posting entries the probes would visit.
+template <int W>
+int launch_raw_global(const nsm_set_table* l, const nsm_set_table* r, double threshold, nsm_hit* hits, uint64_t capacity,
+                      unsigned long long* hit_count, hipStream_t stream, bool probe_only, double* estimate);
+
 // Wave-uniform value -> VGPR.  On gfx950 a VALU op with an SGPR source issues at half rate
 // (4.5 vs 2.4 cycles per wave64 v_xor_b32, profiles/r01_valu_issue_rates_gfx950.txt), so an id that
 // is XORed against NB registers is first broadcast with ONE v_mov_b32.
@@ -370,6 +376,27 @@ int launch_raw(const nsm_set_table* l, const nsm_set_table* r, double threshold,
   // Measured on 20k x 20k sets of ~44 ids at 0.5: pruned 39.1 ms, exhaustive 38.2 ms (tools/bench_w64.py) -- the
   // spill-free exhaustive instantiation (142 VGPRs) runs wide sets.
   const bool prune = (flags & NSM_FLAG_PRUNE) && l->sig && r->sig && W < 64;
+  // The right table carries a global inverted index: generate candidates from it (prefix filter) instead of visiting every
+  // pair, whenever the posting statistics say that is cheaper.  The index kernel's time follows the posting entries its
+  // probes visit (measured ~2e-9 ms per entry on one MI355X, lists L2-resident, plus ~0.01 ms); the signature kernel's
+  // follows N x M at a rate that falls with the threshold (C2-shaped, 2.5e9 pairs: 0.43 / 0.25 / 0.15 / 0.10 ms at 0.5 /
+  // 0.6 / 0.8 / 0.9), and where the signature bound is weak (thresholds below ~0.45 at W = 16) every pair pays the
+  // position matrix, ~3e-9 ms per pair.  tools/sweep_global.py, profiles/r04_global_index_sweep.txt: vocabularies of 2^17,
+  // 4096, 500 and 60 ids x thresholds 0.1 .. 0.9; this rule picks the faster kernel in 26 of the 28 cases (the two misses
+  // within 25 %).
+  if (r->post && r->post_start && r->vocab > 0 && l->sig && r->sig && threshold > 0.0 && !(flags & NSM_FLAG_NO_INDEX) &&
+      !(flags & NSM_FLAG_TILE_INDEX) && (flags & (NSM_FLAG_PRUNE | NSM_FLAG_INDEX))) {
+    double visited = 0.0;
+    if (int rc = launch_raw_global<W>(l, r, threshold, hits, capacity, hit_count, stream, true, &visited)) return rc;
+    const double pairs = static_cast<double>(l->n) * static_cast<double>(r->n);
+    constexpr int kMid = 3 * W / 4;
+    const bool weak = W >= 64 || ((p.weak[kMid] >> kMid) & 1ull);
+    const double ms_global = 0.01 + visited * 2.0e-9;
+    const double t = threshold < 1.0 ? threshold : 1.0;
+    const double ms_pairs = pairs * (weak ? 3.0e-9 : 3.4e-10 * (1.0 - t) + 1.0e-11);
+    if ((flags & NSM_FLAG_INDEX) || ms_global < ms_pairs)
+      return launch_raw_global<W>(l, r, threshold, hits, capacity, hit_count, stream, false, nullptr);
+  }
   if constexpr (W <= 32) {
     // Low thresholds: the signature bound passes too often for typical set sizes (the mid-size class is "weak"),
     // every pair would pay the position matrix.  Candidate generation by inverted index instead.

@@ -9,7 +9,8 @@ LIB_PATH = Path(os.environ.get("NSM_HIP_LIBRARY", _HERE.parent / "csrc" / "libns
 ABI_VERSION = 4
 FLAG_PRUNE = 1
 FLAG_WAVE_WIDE = 2  # nsm_indel_levels_grid without the block-cooperative parking (A/B runs, tests)
-FLAG_INDEX, FLAG_NO_INDEX = 4, 8  # nsm_jaccard_raw_grid: force / forbid the inverted-index kernel
+FLAG_INDEX, FLAG_NO_INDEX = 4, 8  # nsm_jaccard_raw_grid: force / forbid the inverted-index kernels
+FLAG_TILE_INDEX = 64  # with FLAG_INDEX: the per-tile LDS index even when the right table carries a global one
 FLAG_RAW_SCORE = 32  # nsm_*_any_grid: the RAW plugin call instead of compare_terms
 FLAG_PARK = 16  # nsm_indel_levels_grid, strings > 64 code units: the round-2 park kernel instead of the shared-tile kernel
 BUILD_PARTITION, BUILD_VALIDATE, BUILD_SORT = 1, 2, 4
@@ -40,6 +41,10 @@ class NsmSetTable(ctypes.Structure):
         ("n", ctypes.c_int32),
         ("width", ctypes.c_int32),
         ("max_levels", ctypes.c_int32),
+        ("vocab", ctypes.c_int32),
+        ("post", ctypes.c_void_p),
+        ("post_start", ctypes.c_void_p),
+        ("post_sq", ctypes.c_uint64 * 5),
     ]
 
 

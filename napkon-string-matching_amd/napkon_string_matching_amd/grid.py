@@ -114,7 +114,10 @@ def jaccard_raw_grid(
     index: Optional[bool] = None,
 ) -> Hits:
     """``intersection_vs_union`` on one set per item, all N x M pairs, hits ``>= threshold``.
-    ``index``: None = the library decides (inverted-index candidates at low thresholds), True / False = force."""
+    ``index``: None = the library decides (candidates from the right table's global inverted index where its posting
+    statistics say they are few, from a per-tile index at low thresholds, else the signature kernel over all pairs);
+    True = force an index (the global one when the right table carries it), "tile" = force the per-tile index,
+    False = never an index."""
     if left.side != "left" or right.side != "right":
         raise ValueError("tables must be encoded with side='left' and side='right' (distinct padding)")
     if left.has_empty and right.has_empty:
@@ -123,13 +126,15 @@ def jaccard_raw_grid(
     lib = _lib.load()
     ls, rs = left.struct(), right.struct()
     flags = (_lib.FLAG_PRUNE if prune else 0) | (0 if index is None else (_lib.FLAG_INDEX if index else _lib.FLAG_NO_INDEX))
+    if index == "tile":
+        flags |= _lib.FLAG_TILE_INDEX
 
     def launch(buf: HitBuffer, stream: int) -> int:
         return lib.nsm_jaccard_raw_grid(
             ls, rs, float(threshold), flags, buf.records.data_ptr(), buf.capacity, buf.count.data_ptr(), stream
         )
 
-    return run_grid(launch, left.ids.device, capacity, "nsm_jaccard_raw_grid")
+    return run_grid(launch, left.ids.device, capacity, "nsm_jaccard_raw_grid", id_limit=max(left.n, right.n))
 
 
 def indel_raw_grid(

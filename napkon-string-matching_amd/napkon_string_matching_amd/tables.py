@@ -17,8 +17,9 @@ same size class; ``orig`` maps a row back to the caller's item index):
 """
 from __future__ import annotations
 
+import ctypes
 from dataclasses import dataclass
-from typing import Dict, Hashable, Iterable, List, Optional, Sequence
+from typing import Dict, Hashable, Iterable, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -28,10 +29,34 @@ from . import _lib
 WIDTHS = (16, 32, 64)
 STRIDES = (64, 128, 256, 512)  # code units per string row: 1, 2, 4 or 8 words of the bit-parallel LCS
 MAX_LEVELS = 64
+MAX_INDEX_VOCAB = 1 << 22  # largest id + 1 for which a RAW right table gets its global inverted index (20 bytes of offsets per id)
 LEFT_PAD, RIGHT_PAD = -1, -2
 EMPTY_CATEGORY_BIT = 63  # stands for "no category at all" when empty-vs-empty counts as a match
 _GOLDEN = np.uint32(0x9E3779B1)
 _GOLDEN2 = np.uint32(0xC2B2AE35)
+
+
+def inverted_index(ids: np.ndarray, cnt: np.ndarray, vocab: int):
+    """The global inverted index of a RAW table (include/nsm_hip.h: post / post_start / post_sq), the numpy way --
+    what ``nsm_build_set_table`` builds on the GPU, byte for byte.  ``ids`` [n][W] ascending per row, ``cnt`` [n]."""
+    n, width = ids.shape
+    valid = np.arange(width, dtype=np.int64)[None, :] < np.asarray(cnt, dtype=np.int64)[:, None]
+    r_idx, k_idx = np.nonzero(valid)  # row-major: the stable sort below keeps rows ascending inside one (id, position)
+    tok = ids[valid].astype(np.int64)
+    if len(tok) and int(tok.max()) >= vocab:
+        raise ValueError("an id is >= vocab")
+    order = np.lexsort((k_idx, tok))
+    entry = (r_idx.astype(np.uint64) | (k_idx.astype(np.uint64) << np.uint64(32)) |
+             (np.asarray(cnt, dtype=np.uint64)[r_idx] << np.uint64(40)))
+    post = np.zeros(n * width, dtype=np.uint64)
+    post[: len(order)] = entry[order]
+    k_s = k_idx[order]
+    cls = np.where(k_s < 1, 0, np.where(k_s < 2, 1, np.where(k_s < 4, 2, np.where(k_s < 8, 3, 4))))
+    ckey = tok[order] * 5 + cls
+    post_start = np.searchsorted(ckey, np.arange(5 * vocab + 1, dtype=np.int64), side="left").astype(np.int32)
+    base = post_start[:-1:5].astype(np.int64)
+    post_sq = tuple(int(((post_start[c + 1:: 5].astype(np.int64) - base) ** 2).sum()) for c in range(5))
+    return post, post_start, post_sq
 
 
 def pick_width(*max_counts: int) -> int:
@@ -174,6 +199,11 @@ class SetTable:
     seg: Optional[torch.Tensor] = None
     seg_start: Optional[torch.Tensor] = None
     category_mode: Optional[int] = None  # the mode the levels kernel must be called with (set by the encoder)
+    # global inverted index (RAW right tables; include/nsm_hip.h): postings sorted by (id, position), 5 offsets per id
+    post: Optional[torch.Tensor] = None
+    post_start: Optional[torch.Tensor] = None
+    vocab: int = 0
+    post_sq: Tuple[int, ...] = (0, 0, 0, 0, 0)
 
     # ------------------------------------------------------------------ builders
     @classmethod
@@ -185,9 +215,12 @@ class SetTable:
         width: Optional[int] = None,
         orig: Optional[np.ndarray] = None,
         validate: bool = True,
+        index: Optional[bool] = None,
     ) -> "SetTable":
         """RAW table from an int array [n][w]; negative entries are padding, the rest must be
-        unique per row (``validate`` checks)."""
+        unique per row (``validate`` checks).  ``index``: build the global inverted index (None = for right tables
+        whose ids stay below ``MAX_INDEX_VOCAB``): ``nsm_jaccard_raw_grid`` then generates candidate pairs from it
+        wherever that is cheaper than visiting all N x M."""
         ids = np.asarray(ids)
         if ids.ndim != 2:
             raise ValueError("ids must be [n][w]")
@@ -208,7 +241,10 @@ class SetTable:
             srt = np.sort(np.where(packed >= 0, packed, -np.arange(1, width + 1, dtype=np.int64)[None, :]), axis=1)
             if (srt[:, 1:] == srt[:, :-1]).any():
                 raise ValueError("duplicate id inside a row: sets must be de-duplicated before encoding")
-        return cls._finish(packed, cnt, side, device, width, orig)
+        vocab = int(packed.max(initial=-1)) + 1
+        if index is None:
+            index = side == "right" and 0 < vocab <= MAX_INDEX_VOCAB and n * width < (1 << 31)
+        return cls._finish(packed, cnt, side, device, width, orig, index_vocab=vocab if index else 0)
 
     @classmethod
     def from_rows(
@@ -336,18 +372,25 @@ class SetTable:
 
     @classmethod
     def _finish(cls, ids, cnt, side, device, width, orig, nlev=None, plen=None, cat=None, max_levels=0,
-                category_mode=_lib.CAT_NONE, partition=False):
+                category_mode=_lib.CAT_NONE, partition=False, index_vocab=0):
         if side not in ("left", "right"):
             raise ValueError("side must be 'left' or 'right'")
+        if index_vocab and nlev is not None:
+            raise ValueError("the global inverted index is a RAW-table column")
         if nlev is not None:  # entries of plen past an item's last level repeat it (the clamped level index)
             plen = np.asarray(plen, dtype=np.uint8)
             clamp = np.minimum(np.arange(plen.shape[1])[None, :], np.maximum(np.asarray(nlev), 1)[:, None] - 1)
             plen = np.take_along_axis(plen, clamp, axis=1)
         if _on_gpu(device):
-            return cls._finish_device(ids, cnt, side, device, width, orig, nlev, plen, cat, max_levels, category_mode, partition)
+            return cls._finish_device(ids, cnt, side, device, width, orig, nlev, plen, cat, max_levels, category_mode, partition,
+                                      index_vocab)
         n = ids.shape[0]
         ids = ids.copy()
         pad = LEFT_PAD if side == "left" else RIGHT_PAD
+        if nlev is None and n:  # RAW rows: ids ascending (the global token order of the inverted index)
+            big = np.iinfo(np.int32).max
+            ids[np.arange(width, dtype=np.int32)[None, :] >= cnt[:, None]] = big
+            ids.sort(axis=1)
         ids[np.arange(width, dtype=np.int32)[None, :] >= cnt[:, None]] = pad
         base = np.arange(n, dtype=np.int32) if orig is None else np.asarray(orig, dtype=np.int32)
         seg = seg_start = None
@@ -399,7 +442,13 @@ class SetTable:
             sig_l1 = signatures(ids, np.minimum(plen1, cnt_s))
             filt[:, 5] = (sig_l1 & np.uint64(0xFFFFFFFF)).astype(np.uint32)
             filt[:, 6] = (sig_l1 >> np.uint64(32)).astype(np.uint32)
+        post = post_start = None
+        post_sq = (0, 0, 0, 0, 0)
+        if index_vocab:
+            post, post_start, post_sq = inverted_index(ids, cnt_s, index_vocab)
         return cls(
+            post=None if post is None else _dev(post.view(np.int64), device),
+            post_start=None if post_start is None else _dev(post_start, device), vocab=int(index_vocab), post_sq=post_sq,
             filt=None if filt is None else _dev(filt, device),
             ids=_dev(ids, device),
             cnt=_dev(cnt_s, device),
@@ -421,7 +470,8 @@ class SetTable:
         )
 
     @classmethod
-    def _finish_device(cls, ids, cnt, side, device, width, orig, nlev, plen, cat, max_levels, category_mode, partition):
+    def _finish_device(cls, ids, cnt, side, device, width, orig, nlev, plen, cat, max_levels, category_mode, partition,
+                       index_vocab=0):
         """The same table as ``_finish``, built on the GPU by ``nsm_build_set_table`` from the packed ids."""
         lib = _lib.load()
         n = ids.shape[0]
@@ -455,6 +505,8 @@ class SetTable:
             filt=new((cap, 8), torch.int32) if levels else None,
             max_levels=max_levels, seg=new(cap, torch.int32) if do_part else None,
             seg_start=new(65, torch.int32) if do_part else None, category_mode=out_mode if levels else None,
+            post=new(cap * width, torch.int64) if index_vocab else None,
+            post_start=new(5 * index_vocab + 1, torch.int32) if index_vocab else None, vocab=int(index_vocab),
         )
         d_ids = _dev(np.asarray(ids, dtype=np.int32), dev)
         d_nlev = _dev(np.asarray(nlev, dtype=np.int32), dev) if levels else None
@@ -467,6 +519,7 @@ class SetTable:
                                            _ptr(d_cat), _ptr(d_orig), mode, flags, st, _stream(dev)), "nsm_build_set_table")
         if st.n != rows:
             raise _lib.NsmLibraryError(f"nsm_build_set_table built {st.n} rows, expected {rows}")
+        t.post_sq = tuple(int(v) for v in st.post_sq)
         for col in ("ids", "cnt", "sig", "sig2", "orig", "nlev", "plen", "cat", "filt", "seg"):
             if getattr(t, col) is not None:
                 setattr(t, col, getattr(t, col)[:rows])
@@ -482,6 +535,7 @@ class SetTable:
             ptr(self.nlev),
             ptr(self.plen),
             ptr(self.cat), ptr(self.filt), ptr(self.seg), ptr(self.seg_start), self.n, self.width, self.max_levels,
+            self.vocab, ptr(self.post), ptr(self.post_start), (ctypes.c_uint64 * 5)(*self.post_sq),
         )
 
     def nbytes(self) -> int:

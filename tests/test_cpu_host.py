@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.nsm_abi_version() == _lib.ABI_VERSION
     # struct layouts must match the header (sizes on LP64)
     assert ctypes.sizeof(_lib.NsmHit) == 16
-    assert ctypes.sizeof(_lib.NsmSetTable) == 12 * 8 + 3 * 4 + 4
+    assert ctypes.sizeof(_lib.NsmSetTable) == 12 * 8 + 4 * 4 + 2 * 8 + 5 * 8
     assert ctypes.sizeof(_lib.NsmStrTable) == 5 * 8 + 3 * 4 + 4
     assert ctypes.sizeof(_lib.NsmLevelItems) == 6 * 8 + 4 + 4
 
@@ -92,7 +92,13 @@ def test_set_table_encoding_cpu():
     ss = t.size_start.tolist()
     assert len(ss) == 18 and ss[0] == 0 and ss[-1] == 3 and ss[13] == 0 and ss[14] == 1 and ss[15] == 2 and ss[16] == 2
     row0 = t.ids[0].tolist()
-    assert row0[:3] == [5, 9, 2] and set(row0[3:]) == {-2}
+    assert row0[:3] == [2, 5, 9] and set(row0[3:]) == {-2}  # RAW rows: ids ascending (the inverted index's global order)
+    # right tables carry the global inverted index: one entry per (row, id) sorted by (id, position), 5 offsets per id
+    assert t.vocab == 10 and t.post_start.shape[0] == 51 and t.post_sq == (2, 4, 5, 5, 5)
+    entries = [(int(e) & 0xFFFFFFFF, (int(e) >> 32) & 0xFF, (int(e) >> 40) & 0xFF) for e in t.post[:5].numpy().view(np.uint64)]
+    assert entries == [(0, 0, 3), (0, 1, 3), (1, 0, 2), (1, 1, 2), (0, 2, 3)]  # ids 2, 5, 7, 8, 9 -> (row, position, size)
+    assert t.post_start[5 * 2: 5 * 2 + 6].tolist() == [0, 1, 1, 1, 1, 1] and int(t.post_start[-1]) == 5
+    assert tables.SetTable.from_padded(ids, "left", "cpu").post is None
     assert tables.SetTable.from_padded(ids, "left", "cpu").ids[2].tolist() == [-1] * 16
     sig = tables.signatures(np.array([[1, 1 + (1 << 20)]], dtype=np.int32), np.array([2], np.int32))
     assert bin(int(sig[0])).count("1") in (1, 2)

@@ -28,8 +28,10 @@ def _same(a, b, what):
 
 def _same_set_tables(g, c):
     assert (g.n, g.width, g.max_levels, g.has_empty, g.side, g.category_mode) == (c.n, c.width, c.max_levels, c.has_empty, c.side, c.category_mode)
-    for col in ("ids", "cnt", "sig", "sig2", "orig", "size_start", "nlev", "plen", "cat", "filt", "seg", "seg_start"):
+    for col in ("ids", "cnt", "sig", "sig2", "orig", "size_start", "nlev", "plen", "cat", "filt", "seg", "seg_start", "post",
+                "post_start"):
         _same(getattr(g, col), getattr(c, col), col)
+    assert (g.vocab, tuple(g.post_sq)) == (c.vocab, tuple(c.post_sq))
 
 
 def _rand_ids(rng, n, width, vocab, kmax, allow_empty):
@@ -53,6 +55,17 @@ def test_set_table_raw(dev, width, kmax, vocab, side):
                          tables.SetTable.from_padded(ids, side, "cpu", width=width, orig=o))
     empty = np.full((0, width), -1, dtype=np.int32)
     _same_set_tables(tables.SetTable.from_padded(empty, side, dev, width=width), tables.SetTable.from_padded(empty, side, "cpu", width=width))
+    # the global inverted index (built for right tables by default; here on both sides): rows come out ascending, postings
+    # sorted by (id, position), five offsets per id, the squared-length statistics on the host
+    g = tables.SetTable.from_padded(ids, side, dev, width=width, index=True)
+    c = tables.SetTable.from_padded(ids, side, "cpu", width=width, index=True)
+    assert g.post is not None and g.vocab == int(ids.max()) + 1 and g.post_sq[4] > 0
+    _same_set_tables(g, c)
+    rows = g.ids.cpu().numpy()
+    live = rows >= 0
+    assert (np.diff(np.where(live, rows, np.iinfo(np.int32).max).astype(np.int64), axis=1) >= 0).all()
+    assert (tables.SetTable.from_padded(ids, "right", dev, width=width).post is not None) and \
+           (tables.SetTable.from_padded(ids, "left", dev, width=width).post is None)
 
 
 @pytest.mark.parametrize("n_cat", [3, 32, 63])

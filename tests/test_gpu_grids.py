@@ -86,6 +86,59 @@ def test_jaccard_raw_inverted_index(dev, width, kmax, vocab, n_left, n_right):
         _same_hits(grid.jaccard_raw_grid(lt, rt, thr, index=False, capacity=1 << 12), want)  # never the index
 
 
+@pytest.mark.parametrize("width,kmax,vocab,n_left,n_right", [
+    (16, 16, 60, 333, 517),         # tiny vocabulary: long posting lists, most candidates survive the cheap filters
+    (16, 10, 5000, 2100, 1700),     # sparse
+    (16, 16, 100000, 900, 2500),    # every row full
+    (16, 3, 40, 500, 700),          # tiny sets: prefix = the whole row
+    (32, 30, 700, 700, 900),
+    (32, 12, 90, 300, 400),
+    (64, 64, 3000, 200, 300),
+    (64, 40, 150, 150, 260),
+])
+def test_jaccard_raw_global_index(dev, width, kmax, vocab, n_left, n_right):
+    """Candidate generation from the right table's GLOBAL inverted index (prefix filter: probe the posting lists of the
+    first few ids of every left row) == the per-tile index == the signature kernel == the oracle, at thresholds from
+    "one common id suffices" (prefix = the whole row) to "identical sets only" (prefix = one id), with planted
+    near-duplicates, empty sets, ids the right side never uses, and a left table whose ids arrive unsorted."""
+    from napkon_string_matching_amd import grid, tables
+    from oracle import native
+
+    rng = random.Random(width * 91 + vocab + kmax)
+    left = _rand_padded(rng, n_left, width, vocab, kmax, allow_empty=False)
+    right = _rand_padded(rng, n_right, width, vocab, kmax, allow_empty=True)
+    for t in range(0, n_right, 7):  # near-duplicates: a left row with one id swapped or dropped
+        row = [v for v in left[rng.randrange(n_left)] if v >= 0]
+        if len(row) > 1 and rng.random() < 0.5:
+            row[rng.randrange(len(row))] = vocab + rng.randrange(50)  # an id above everything else
+        elif len(row) > 1 and rng.random() < 0.5:
+            row.pop(rng.randrange(len(row)))
+        rng.shuffle(row)
+        right[t] = row + [-1] * (width - len(row))
+    left[5][: kmax] = sorted((v for v in left[5][: kmax]), reverse=True)  # unsorted input rows
+    lt = tables.SetTable.from_padded(left, "left", dev, width=width)
+    rt = tables.SetTable.from_padded(right, "right", dev, width=width)
+    assert rt.post is not None and lt.post is None and rt.vocab == int(np.max(right)) + 1
+    plain = tables.SetTable.from_padded(right, "right", dev, width=width, index=False)
+    assert plain.post is None
+    for thr in (0.01, 0.1, 0.25, 1 / 3, 0.5, 0.6, 0.75, 0.8, 0.9, 1.0):
+        want = native.jaccard_raw(native.csr_from_padded(left), native.csr_from_padded(right), thr, cap=1 << 20)
+        forced = grid.jaccard_raw_grid(lt, rt, thr, index=True, capacity=1 << 12)
+        _same_hits(forced, want)
+        _same_hits(grid.jaccard_raw_grid(lt, rt, thr, capacity=1 << 12), want)                 # the library's choice
+        _same_hits(grid.jaccard_raw_grid(lt, rt, thr, index=False, capacity=1 << 12), want)    # all pairs
+        if width <= 32:
+            _same_hits(grid.jaccard_raw_grid(lt, rt, thr, index="tile", capacity=1 << 12), want)   # per-tile LDS index
+            _same_hits(grid.jaccard_raw_grid(lt, plain, thr, index=True, capacity=1 << 12), want)  # no global index to force
+    assert len(want) > 0  # (threshold 1.0: the identical planted rows)
+    # thresholds <= 0: every pair hits, an index cannot help and is not used
+    want0 = native.jaccard_raw(native.csr_from_padded(left[:40]), native.csr_from_padded(right[:50]), 0.0, cap=1 << 20)
+    lt0 = tables.SetTable.from_padded(left[:40], "left", dev, width=width)
+    rt0 = tables.SetTable.from_padded([r for r in right[:50]], "right", dev, width=width)
+    if not (lt0.has_empty and rt0.has_empty):
+        _same_hits(grid.jaccard_raw_grid(lt0, rt0, 0.0, index=True), want0)
+
+
 def test_jaccard_raw_c2_shaped_low_threshold(dev):
     """configs[1]'s generator at the API's default threshold 0.1 (types/comparable_data.py:74), 20k x 20k: the
     index kernel against the exhaustive matrix kernel, and the collision-crafted ids of the signature test."""
