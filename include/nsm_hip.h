@@ -285,7 +285,8 @@ int nsm_build_level_items(const int32_t* first_in, const int32_t* nlev_in, const
  * no derived columns, no pruning: every pair that passes the category predicate is scored in full.  Meant for the FEW
  * items that need it -- a host routes (wide items x all) and (all x wide items) through here and the rest through the
  * grids above (napkon_string_matching_amd/wide.py does).  Caps: 4096 code units per string, 1023 symbols, 65535 ids
- * per item, 64 levels; beyond them NSM_E_UNSUPPORTED.
+ * per item; 64 levels in the nested set layout (none in the independent one, none for strings); beyond them
+ * NSM_E_UNSUPPORTED.
  */
 typedef struct nsm_any_strings {
   const uint16_t* codes;   /* device: code units of all rows, concatenated */
@@ -314,6 +315,11 @@ typedef struct nsm_any_sets {
   int32_t n;
   int32_t max_levels;      /* row stride of plen, the same on both sides */
   int32_t max_ids;         /* most ids in one item (<= 65535) */
+  const int32_t* first;    /* NULL: the suffix-nested layout above (at most 64 levels).  Otherwise INDEPENDENT levels -- what the
+                              reference scores when a tokenizer makes level l differ from "level l - 1 plus more"
+                              (types/comparable_data.py:283-299 re-tokenises every suffix), and items of any depth (a
+                              `Variable` of 100 characters has 100 levels, :567-574): device int32 [n], level l of item k is
+                              ROW first[k] + l of `offset` (int64 [rows + 1]), its ids sorted by id; lv / plen unused */
 } nsm_any_sets;
 
 #define NSM_FLAG_RAW_SCORE 32u /* nsm_*_any_grid: score = score_func(level 0, level 0) (the RAW plugin call) instead of

@@ -151,7 +151,8 @@ __global__ __launch_bounds__(kWave) void jaccard_any_kernel(
     const uint64_t* __restrict__ lcat, const int32_t* __restrict__ rids, const uint8_t* __restrict__ rlv,
     const long long* __restrict__ roff, const int32_t* __restrict__ rnlev, const int32_t* __restrict__ rplen,
     const int32_t* __restrict__ rorig, const uint64_t* __restrict__ rcat, int max_levels, nsm_hit* __restrict__ hits,
-    unsigned long long* __restrict__ count, const AnyParams p) {
+    unsigned long long* __restrict__ count, const AnyParams p, const int32_t* __restrict__ lfirst,
+    const int32_t* __restrict__ rfirst) {
   // LDS: [65][64] u16: per lane, ids first common from step s on ([step][lane])
   __shared__ uint16_t s_first[(kAnyMaxLevels + 1) * kWave];
   const int lane = threadIdx.x;
@@ -159,8 +160,10 @@ __global__ __launch_bounds__(kWave) void jaccard_any_kernel(
   const bool valid = j < p.n_right;
   const int jc = valid ? j : p.n_right - 1;
   const int lr = rnlev[jc];
-  const long long rb0 = roff[jc];
-  const int nb = static_cast<int>(roff[jc + 1] - rb0);
+  const bool independent = lfirst != nullptr;  // (both sides alike: checked by the launcher)
+  const long long rb0 = independent ? 0 : roff[jc];
+  const int nb = independent ? 0 : static_cast<int>(roff[jc + 1] - rb0);
+  const int rf = independent ? rfirst[jc] : 0;
   const uint64_t catr = p.cat_mode != NSM_CAT_NONE ? rcat[jc] : 0ull;
   const int i0 = blockIdx.y * p.rows_per_chunk, i1 = min(p.n_left, i0 + p.rows_per_chunk);
   for (int i = i0; i < i1; ++i) {
@@ -174,6 +177,46 @@ __global__ __launch_bounds__(kWave) void jaccard_any_kernel(
       continue;
     }
     ok = ok && lr > 0;
+    if (independent) {
+      // every step's two level rows are merged on their own (lane-local): nothing is assumed about how the levels of an
+      // item relate, and an item may have any number of them
+      double score = 0.0, factor = 1.0, q = 0.0;
+      if (ok) {
+        const int lf = lfirst[i];
+        const int S = p.raw ? 0 : max(ll, lr);
+        int prev_a = -1, prev_b = -1;
+        for (int s = p.raw ? 0 : 1; s <= S; ++s) {
+          factor *= 0.5;
+          const int a = max(0, min(s, ll - 1)), b = max(0, min(s, lr - 1));
+          if (a != prev_a || b != prev_b) {
+            prev_a = a;
+            prev_b = b;
+            const long long a0 = loff[lf + a], b0 = roff[rf + b];
+            const int na = static_cast<int>(loff[lf + a + 1] - a0), nb2 = static_cast<int>(roff[rf + b + 1] - b0);
+            int x = 0, y = 0, inter = 0;
+            int ida = na > 0 ? lids[a0] : 0, idb = nb2 > 0 ? rids[b0] : 0;
+            while (x < na && y < nb2) {
+              if (ida == idb) {
+                ++inter; ++x; ++y;
+                if (x < na) ida = lids[a0 + x];
+                if (y < nb2) idb = rids[b0 + y];
+              } else if (ida < idb) {
+                ++x;
+                if (x < na) ida = lids[a0 + x];
+              } else {
+                ++y;
+                if (y < nb2) idb = rids[b0 + y];
+              }
+            }
+            const int uni = na + nb2 - inter;
+            q = uni > 0 ? static_cast<double>(inter) / static_cast<double>(uni) : 0.0;  // (0 / 0: the host raises beforehand)
+          }
+          score = p.raw ? q : score + q * factor;
+        }
+      }
+      emit_hits_wave(hits, p.cap, count, ok && score >= p.threshold, score, lorig[i], rorig[jc]);
+      continue;
+    }
     const long long la0 = loff[i];
     const int na = static_cast<int>(loff[i + 1] - la0);
     const int S = p.raw ? 1 : max(ll, lr);
@@ -272,10 +315,14 @@ extern "C" int nsm_jaccard_any_grid(const nsm_any_sets* left, const nsm_any_sets
     set_error("nsm_jaccard_any_grid: null argument");
     return NSM_E_BADARG;
   }
-  if (left->max_levels != right->max_levels || left->max_levels < 1 || left->max_levels > kAnyMaxLevels) {
-    set_error("nsm_jaccard_any_grid: max_levels %d / %d (both sides alike, 1..%d)", left->max_levels, right->max_levels,
-              kAnyMaxLevels);
+  if ((left->first == nullptr) != (right->first == nullptr)) {
+    set_error("nsm_jaccard_any_grid: both sides in the same layout (nested, or independent levels with `first`)");
     return NSM_E_BADARG;
+  }
+  if (!left->first && (left->max_levels != right->max_levels || left->max_levels < 1 || left->max_levels > kAnyMaxLevels)) {
+    set_error("nsm_jaccard_any_grid: max_levels %d / %d (both sides alike, 1..%d in the nested layout)", left->max_levels,
+              right->max_levels, kAnyMaxLevels);
+    return left->max_levels > kAnyMaxLevels || right->max_levels > kAnyMaxLevels ? NSM_E_UNSUPPORTED : NSM_E_BADARG;
   }
   if (left->max_ids > 65535 || right->max_ids > 65535) {
     set_error("nsm_jaccard_any_grid: an item has more than 65535 ids");
@@ -298,6 +345,6 @@ extern "C" int nsm_jaccard_any_grid(const nsm_any_sets* left, const nsm_any_sets
   hipLaunchKernelGGL(jaccard_any_kernel, grid, dim3(kWave), 0, static_cast<hipStream_t>(stream), left->ids, left->lv,
                      reinterpret_cast<const long long*>(left->offset), left->nlev, left->plen, left->orig, left->cat, right->ids,
                      right->lv, reinterpret_cast<const long long*>(right->offset), right->nlev, right->plen, right->orig,
-                     right->cat, left->max_levels, hits, hit_count, p);
+                     right->cat, left->max_levels, hits, hit_count, p, left->first, right->first);
   return hip_status(hipGetLastError(), "jaccard_any_kernel launch");
 }

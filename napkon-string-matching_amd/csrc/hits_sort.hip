@@ -8,14 +8,23 @@
 //   * up to 8192 live records (the common case): ONE workgroup sorts 128-bit integer keys
 //     (~score bits, i, j) with a bitonic network in LDS (16 bytes per record, 128 KB at most) and
 //     writes the records back in place -- a single launch;
-//   * more: bitonic network, "flip" form (all comparators point the same way), which needs no
-//     padding to a power of two.  Every comparator pass whose partner distance is below 2048 stays
+//   * more: ONE radix sort (rocPRIM, a library sort) over 128-bit keys built in place from the records -- inverted
+//     score bits, then i, then j, packed so that only the bits that can differ are sorted (the caller's id_limit bounds
+//     i and j: 94 key bits = 12 digit passes for a 20 000-item cohort instead of 16).  The record IS its key, so the
+//     sort moves 16 bytes per record and pass and nothing else.  Its temporary storage is stream-ordered
+//     (hipMallocAsync / hipFreeAsync inside the call).  10.5 M hits (the reference's default configuration at the cache
+//     threshold): 6 ms of bitonic passes before, see DESIGN.md for the measured radix time;
+//   * on a stream that is being captured into a graph (no allocation allowed): bitonic network, "flip" form (all
+//     comparators point the same way), which needs no padding to a power of two.  Every comparator pass whose partner distance is below 2048 stays
 //     inside an aligned 2048-record tile, so those passes run fused in LDS (one launch sorts all
 //     tiles, one launch finishes each larger merge); only the passes with distance >= 2048 are
 //     separate launches over global memory.  Passes beyond the live count exit immediately.
 #include "nsm_common.hpp"
 
 #include <atomic>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
 
 namespace nsm {
 
@@ -167,12 +176,95 @@ __global__ __launch_bounds__(kBlock) void bitonic_tile_kernel(nsm_hit* __restric
   for (int t = threadIdx.x; t < m; t += kBlock) hits[base + t] = tile[t];
 }
 
+// ---- radix path: record <-> 128-bit key, in place
+struct Key128 {
+  unsigned long long lo, hi;  // (value = hi : lo; the decomposer hands rocPRIM hi first = most significant)
+};
+static_assert(sizeof(Key128) == sizeof(nsm_hit), "the record is its own key");
+struct Key128Decomposer {
+  __host__ __device__ ::rocprim::tuple<unsigned long long&, unsigned long long&> operator()(Key128& k) const {
+    return ::rocprim::tuple<unsigned long long&, unsigned long long&>(k.hi, k.lo);
+  }
+};
+
+// key = score_key : i' : j' with i', j' in `bits` bits each (bits == 32: the ids' sign bit flipped, any int32 sorts right)
+__global__ __launch_bounds__(kBlock) void hits_to_keys_kernel(nsm_hit* __restrict__ hits, unsigned long long capacity,
+                                                              const unsigned long long* __restrict__ count,
+                                                              unsigned long long bound, int bits) {
+  const unsigned long long n = live_count(count, capacity);
+  const unsigned long long t = static_cast<unsigned long long>(blockIdx.x) * kBlock + threadIdx.x;
+  if (t >= bound) return;
+  Key128* keys = reinterpret_cast<Key128*>(hits);
+  Key128 k;
+  if (t < n) {
+    const nsm_hit h = hits[t];
+    const unsigned long long sk = score_key(h.score);
+    const uint32_t flip = bits == 32 ? 0x80000000u : 0u;
+    const unsigned long long ids = (static_cast<unsigned long long>(static_cast<uint32_t>(h.i) ^ flip) << bits) |
+                                   static_cast<unsigned long long>(static_cast<uint32_t>(h.j) ^ flip);
+    const int idb = 2 * bits;  // 2 .. 64
+    k.lo = idb == 64 ? ids : (ids | (sk << idb));
+    k.hi = idb == 64 ? sk : (sk >> (64 - idb));
+  } else {
+    k.lo = ~0ull;  // padding up to the host's bound sorts last
+    k.hi = ~0ull;
+  }
+  keys[t] = k;
+}
+
+__global__ __launch_bounds__(kBlock) void keys_to_hits_kernel(const Key128* __restrict__ keys, nsm_hit* __restrict__ hits,
+                                                              unsigned long long capacity,
+                                                              const unsigned long long* __restrict__ count,
+                                                              unsigned long long bound, int bits) {
+  unsigned long long n = live_count(count, capacity);
+  if (n > bound) n = bound;
+  const unsigned long long t = static_cast<unsigned long long>(blockIdx.x) * kBlock + threadIdx.x;
+  if (t >= n) return;
+  const Key128 k = keys[t];
+  const int idb = 2 * bits;
+  const unsigned long long sk = idb == 64 ? k.hi : ((k.hi << (64 - idb)) | (k.lo >> idb));
+  const unsigned long long ids = idb == 64 ? k.lo : (k.lo & ((1ull << idb) - 1ull));
+  const uint32_t flip = bits == 32 ? 0x80000000u : 0u;
+  const unsigned long long asc = ~sk;
+  const unsigned long long fbits = asc ^ ((asc >> 63) ? (1ull << 63) : ~0ull);
+  nsm_hit h;
+  h.score = __longlong_as_double(static_cast<long long>(fbits));
+  h.i = static_cast<int32_t>(static_cast<uint32_t>(ids >> bits) ^ flip);
+  h.j = static_cast<int32_t>(static_cast<uint32_t>(bits == 32 ? ids : (ids & ((1ull << bits) - 1ull))) ^ flip);
+  hits[t] = h;
+}
+
+static int radix_sort_hits(nsm_hit* hits, nsm_hit* scratch, unsigned long long capacity, const unsigned long long* hit_count,
+                           unsigned long long bound, uint32_t id_limit, hipStream_t s) {
+  int bits = 32;
+  if (id_limit > 0 && id_limit <= 0x80000000u) {
+    bits = 1;
+    while ((1ull << bits) < id_limit) ++bits;
+  }
+  const unsigned blocks = static_cast<unsigned>((bound + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(hits_to_keys_kernel, dim3(blocks), dim3(kBlock), 0, s, hits, capacity, hit_count, bound, bits);
+  ::rocprim::double_buffer<Key128> keys(reinterpret_cast<Key128*>(hits), reinterpret_cast<Key128*>(scratch));
+  const unsigned end_bit = static_cast<unsigned>(64 + 2 * bits);
+  size_t bytes = 0;
+  hipError_t e = ::rocprim::radix_sort_keys(nullptr, bytes, keys, static_cast<size_t>(bound), Key128Decomposer{}, 0u, end_bit, s);
+  if (e != hipSuccess) return hip_status(e, "radix_sort_keys (size)");
+  void* temp = nullptr;
+  e = hipMallocAsync(&temp, bytes ? bytes : 1, s);
+  if (e != hipSuccess) return hip_status(e, "nsm_sort_hits: stream-ordered scratch");
+  e = ::rocprim::radix_sort_keys(temp, bytes, keys, static_cast<size_t>(bound), Key128Decomposer{}, 0u, end_bit, s);
+  (void)hipFreeAsync(temp, s);
+  if (e != hipSuccess) return hip_status(e, "radix_sort_keys");
+  // (keys.current() is wherever the last digit pass left the result; the records go back to `hits` either way -- in place
+  // when that is `hits` itself: one thread reads and rewrites its own 16 bytes)
+  hipLaunchKernelGGL(keys_to_hits_kernel, dim3(blocks), dim3(kBlock), 0, s, keys.current(), hits, capacity, hit_count, bound, bits);
+  return hip_status(hipGetLastError(), "nsm_sort_hits (radix)");
+}
+
 }  // namespace nsm
 
 extern "C" int nsm_sort_hits(nsm_hit* hits, nsm_hit* scratch, uint64_t capacity, const unsigned long long* hit_count,
                              uint64_t n_hint, uint32_t id_limit, void* stream) {
   using namespace nsm;
-  (void)id_limit;
   if (!hits || !hit_count) {
     set_error("nsm_sort_hits: null argument");
     return NSM_E_BADARG;
@@ -209,6 +301,18 @@ extern "C" int nsm_sort_hits(nsm_hit* hits, nsm_hit* scratch, uint64_t capacity,
     set_error("nsm_sort_hits: scratch buffer required");
     return NSM_E_BADARG;
   }
+  if (bound > 0x7fffffffull * 32ull) {
+    set_error("nsm_sort_hits: capacity too large");
+    return NSM_E_UNSUPPORTED;
+  }
+  hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &capture) != hipSuccess) capture = hipStreamCaptureStatusNone;
+#ifndef NSM_SORT_BITONIC
+  // (the single-workgroup kernel above has already returned without touching anything when more than 8192 records are live;
+  // when fewer are, it has sorted them and the radix sort below re-sorts a sorted list: correct, and only paid by callers
+  // that pass no n_hint although few records are live)
+  if (capture == hipStreamCaptureStatusNone) return radix_sort_hits(hits, scratch, capacity, hit_count, bound, id_limit, s);
+#endif
   unsigned long long blocks64 = (bound + kBlock - 1) / kBlock;
   const unsigned blocks = static_cast<unsigned>(blocks64 < 8192 ? blocks64 : 8192);
   unsigned long long tiles64 = (bound + kTile - 1) / kTile;

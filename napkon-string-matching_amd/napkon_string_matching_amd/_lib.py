@@ -74,7 +74,7 @@ class NsmAnyItems(ctypes.Structure):
 class NsmAnySets(ctypes.Structure):
     _fields_ = [("ids", ctypes.c_void_p), ("lv", ctypes.c_void_p), ("offset", ctypes.c_void_p), ("nlev", ctypes.c_void_p),
                 ("plen", ctypes.c_void_p), ("orig", ctypes.c_void_p), ("cat", ctypes.c_void_p), ("n", ctypes.c_int32),
-                ("max_levels", ctypes.c_int32), ("max_ids", ctypes.c_int32)]
+                ("max_levels", ctypes.c_int32), ("max_ids", ctypes.c_int32), ("first", ctypes.c_void_p)]
 
 
 class NsmLevelItems(ctypes.Structure):

@@ -36,6 +36,11 @@ _GOLDEN = np.uint32(0x9E3779B1)
 _GOLDEN2 = np.uint32(0xC2B2AE35)
 
 
+class IrregularLevels(NotImplementedError):
+    """An item the suffix-nested fast layout cannot hold (levels that are not nested, or more than 64 of them): the
+    host routes such items -- and only them -- through the general kernels (wide.py)."""
+
+
 def inverted_index(ids: np.ndarray, cnt: np.ndarray, vocab: int):
     """The global inverted index of a RAW table (include/nsm_hip.h: post / post_start / post_sq), the numpy way --
     what ``nsm_build_set_table`` builds on the GPU, byte for byte.  ``ids`` [n][W] ascending per row, ``cnt`` [n]."""
@@ -293,7 +298,7 @@ class SetTable:
         nlev = np.fromiter((len(levels) for levels in items), dtype=np.int64, count=n)
         if n and int(nlev.max()) > MAX_LEVELS:
             k = int(np.argmax(nlev > MAX_LEVELS))
-            raise NotImplementedError(f"item {k} has {int(nlev[k])} levels > {MAX_LEVELS}")
+            raise IrregularLevels(f"item {k} has {int(nlev[k])} levels > {MAX_LEVELS}")
         n_levels = int(nlev.sum())
         level_len = np.fromiter((len(level) for levels in items for level in levels), dtype=np.int64, count=n_levels)
         ids_of = vocab._ids  # token -> id, new tokens numbered in order of first appearance
@@ -338,9 +343,9 @@ class SetTable:
         bad = live & (distinct != plen_full)
         if bad.any():
             k, lv = (int(v[0]) for v in np.nonzero(bad))
-            raise NotImplementedError(
-                f"item {k}: level {lv} does not contain level {lv - 1}; only suffix-nested levels (what "
-                "gen_comp_value produces) are supported on the GPU")
+            raise IrregularLevels(
+                f"item {k}: level {lv} does not contain level {lv - 1}; the suffix-nested fast layout (what "
+                "gen_comp_value produces with a whitespace tokenizer) cannot hold it")
         return ids, plen_full.astype(np.uint8), nlev.astype(np.int32), max_levels, width
 
     @classmethod

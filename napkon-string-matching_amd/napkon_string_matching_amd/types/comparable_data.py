@@ -315,7 +315,8 @@ class ComparableData:
             raise IndexError("list index out of range")
         if plugin.kind == "sets":
             sets = lambda levels: [list(score_functions.set_operand(lv)) for lv in levels]
-            if min(_empty_step_limit(sets(left)), _empty_step_limit(sets(right))) >= 1:
+            sl, sr = sets(left), sets(right)
+            if _divides_by_zero(sl, _empty_levels(sl), sr, _empty_levels(sr)):
                 raise ZeroDivisionError("division by zero")  # an empty-vs-empty level is visited
         hits = _levels_grid(plugin, [list(left)], [list(right)], float("-inf"), None, None)
         return float(hits.score[0])
@@ -584,16 +585,17 @@ def _first_surviving_pair(n_l: int, n_r: int, banned: set) -> Optional[Tuple[int
     return None
 
 
-def _empty_step_limit(levels: Sequence[Sequence]) -> int:
-    """Largest step s >= 1 at which the item presents an EMPTY level (levels are nested, so the
-    empty ones are a prefix): _INF when every level is empty, otherwise (#empty levels) - 1."""
-    empty = 0
-    for lv in levels:
-        if len(lv) == 0:
-            empty += 1
-        else:
-            break
-    return _INF if empty == len(levels) else empty - 1
+def _empty_levels(levels: Sequence[Sequence]) -> frozenset:
+    """Indices of the item's EMPTY levels that a step can reach: step s >= 1 uses level min(s, L - 1), so level 0 only
+    counts for a one-level item.  (Nested levels: the empty ones are a prefix; the reference's tokenizer may yield any.)"""
+    n = len(levels)
+    return frozenset(k for k, lv in enumerate(levels) if len(lv) == 0 and (k >= 1 or n == 1))
+
+
+def _divides_by_zero(levels_l, empty_l: frozenset, levels_r, empty_r: frozenset) -> bool:
+    """Does ``compare_terms`` reach a step at which BOTH level sets are empty (score_functions.py:13)?"""
+    n_l, n_r = len(levels_l), len(levels_r)
+    return any(min(s, n_l - 1) in empty_l and min(s, n_r - 1) in empty_r for s in range(1, max(n_l, n_r) + 1))
 
 
 def _raise_first_pair_error(is_sets, levels_l, levels_r, nlev_l, nlev_r, n_r, survives, extra_hits) -> None:
@@ -610,13 +612,14 @@ def _raise_first_pair_error(is_sets, levels_l, levels_r, nlev_l, nlev_r, n_r, su
             if nlev_l[i] != 0:
                 candidates.append((i, int(j), IndexError))
     if is_sets:
-        lim_l = [(_empty_step_limit(v) if len(v) else -1) for v in levels_l]
-        lim_r = [(_empty_step_limit(v) if len(v) else -1) for v in levels_r]
-        sus_l = [i for i, v in enumerate(lim_l) if v >= 1]
-        sus_r = [j for j, v in enumerate(lim_r) if v >= 1]
+        emp_l = [_empty_levels(v) for v in levels_l]
+        emp_r = [_empty_levels(v) for v in levels_r]
+        sus_l = [i for i, v in enumerate(emp_l) if v]
+        sus_r = [j for j, v in enumerate(emp_r) if v]
         for i in sus_l:
             for j in sus_r:
-                candidates.append((i, j, ZeroDivisionError))
+                if _divides_by_zero(levels_l[i], emp_l[i], levels_r[j], emp_r[j]):
+                    candidates.append((i, j, ZeroDivisionError))
     best = None
     for i, j, exc in candidates:
         if survives(i, j):
@@ -636,6 +639,43 @@ def _may_be_wide_sets(*sides) -> bool:
     return any(size(it[-1]) > 64 for items in sides for it in items if len(it))
 
 
+def _fast_jaccard_levels(levels_l, levels_r, as_set_levels, threshold, cat_l, cat_r, cat_mode, dev) -> grid.Hits:
+    """The suffix-nested fast layout of both sides + ``nsm_jaccard_levels_grid``; raises ``tables.IrregularLevels`` when an
+    item does not fit it."""
+    part = tables.partition_allowed(cat_mode, cat_l, cat_r)
+    memo = ComparableData._item_memo
+    if memo is not None:
+        # inside item_memo(): one vocabulary for the whole run, every item encoded once (tables.LevelPool,
+        # keyed by the identity of the memoised level lists)
+        pool = memo.setdefault(("level pool",), tables.LevelPool())
+        vocab = pool.vocab
+        rows = [pool.rows_keyed(levels, as_set_levels) for levels in (levels_l, levels_r)]
+        width = tables.pick_width(*(int((ids >= 0).sum(axis=1).max(initial=1)) for ids, _, _ in rows))
+        sides = []
+        for (ids, plen, nlev), side, cat in zip(rows, ("left", "right"), (cat_l, cat_r)):
+            deepest = max(4, -(-(int(nlev.max()) if len(nlev) else 1) // 4) * 4)
+            sides.append(tables.SetTable.from_nested_arrays(ids, plen[:, :deepest], nlev, side, dev, categories=cat,
+                                                            width=width, category_mode=cat_mode, partition=part))
+        lt, rt = sides
+    else:
+        vocab = tables.Vocabulary()
+        sl, sr = [as_set_levels(it) for it in levels_l], [as_set_levels(it) for it in levels_r]
+        width = tables.pick_width(
+            max((len(set(it[-1])) for it in sl if it), default=1), max((len(set(it[-1])) for it in sr if it), default=1)
+        )
+        lt = tables.SetTable.from_levels(sl, "left", dev, vocab, width=width, categories=cat_l, category_mode=cat_mode,
+                                         partition=part)
+        rt = tables.SetTable.from_levels(sr, "right", dev, vocab, width=width, categories=cat_r,
+                                         category_mode=cat_mode, partition=part)
+    if len(vocab) >= 1 << 25:
+        raise NotImplementedError("vocabulary of 2^25 or more distinct tokens")
+    # the library picks the inverted-index kernel from the threshold alone (it cannot see the vocabulary); the host
+    # can: with a large vocabulary few pairs share an id and the index wins at every threshold (3 x 100k^2 items of
+    # ~8 ids: 20k words 2.1 vs 2.2 ms at 0.7 and 4.2 vs 22 ms at 0.1; 2^17 words 1.0 vs 2.3 ms and 1.8 vs 20.9 ms)
+    use_index = True if (threshold > 0 and len(vocab) >= 8192) else None
+    return grid.jaccard_levels_grid(lt, rt, threshold, category_mode=cat_mode, index=use_index)
+
+
 def _levels_grid(plugin, levels_l, levels_r, threshold, cat_l, cat_r, cat_mode=_lib.CAT_NONE) -> grid.Hits:
     """Encode both sides' levels for ``plugin`` and run the levels grid on the current device."""
     import torch
@@ -649,48 +689,30 @@ def _levels_grid(plugin, levels_l, levels_r, threshold, cat_l, cat_r, cat_mode=_
     cut = lambda cat, idx: None if cat is None else np.asarray(cat)[np.asarray(idx, dtype=np.int64)]
     if plugin.kind == "sets":
         as_set_levels = lambda it: [lv if isinstance(lv, list) else lv.split() for lv in it]
-        split = wide.wide_set_items([as_set_levels(it) for it in levels_l], [as_set_levels(it) for it in levels_r]) \
-            if _may_be_wide_sets(levels_l, levels_r) else None
-        if split is not None:
-            # items of more than 64 distinct tokens leave the fast path (wide.py); the rest is scored as always
+        def split_route(split):
+            # items of more than 64 distinct tokens / more than 64 levels / levels that are not suffix-nested leave the fast
+            # path (wide.py: general kernel, every step's level sets scored on their own); the rest is scored as always
             fast = lambda li, ri: _levels_grid(plugin, sub(levels_l, li), sub(levels_r, ri), threshold, cut(cat_l, li),
                                                cut(cat_r, ri), cat_mode)
             general = lambda li, ri: wide.jaccard_any_grid(
                 [as_set_levels(levels_l[k]) for k in li], [as_set_levels(levels_r[k]) for k in ri], threshold, cut(cat_l, li),
                 cut(cat_r, ri), cat_mode, device=dev)
             return wide.split_grid(split[0], split[1], fast, general)
-        part = tables.partition_allowed(cat_mode, cat_l, cat_r)
-        memo = ComparableData._item_memo
-        if memo is not None:
-            # inside item_memo(): one vocabulary for the whole run, every item encoded once (tables.LevelPool,
-            # keyed by the identity of the memoised level lists)
-            pool = memo.setdefault(("level pool",), tables.LevelPool())
-            vocab = pool.vocab
-            rows = [pool.rows_keyed(levels, as_set_levels) for levels in (levels_l, levels_r)]
-            width = tables.pick_width(*(int((ids >= 0).sum(axis=1).max(initial=1)) for ids, _, _ in rows))
-            sides = []
-            for (ids, plen, nlev), side, cat in zip(rows, ("left", "right"), (cat_l, cat_r)):
-                deepest = max(4, -(-(int(nlev.max()) if len(nlev) else 1) // 4) * 4)
-                sides.append(tables.SetTable.from_nested_arrays(ids, plen[:, :deepest], nlev, side, dev, categories=cat,
-                                                                width=width, category_mode=cat_mode, partition=part))
-            lt, rt = sides
-        else:
-            vocab = tables.Vocabulary()
-            sl, sr = [as_set_levels(it) for it in levels_l], [as_set_levels(it) for it in levels_r]
-            width = tables.pick_width(
-                max((len(set(it[-1])) for it in sl if it), default=1), max((len(set(it[-1])) for it in sr if it), default=1)
-            )
-            lt = tables.SetTable.from_levels(sl, "left", dev, vocab, width=width, categories=cat_l, category_mode=cat_mode,
-                                             partition=part)
-            rt = tables.SetTable.from_levels(sr, "right", dev, vocab, width=width, categories=cat_r,
-                                             category_mode=cat_mode, partition=part)
-        if len(vocab) >= 1 << 25:
-            raise NotImplementedError("vocabulary of 2^25 or more distinct tokens")
-        # the library picks the inverted-index kernel from the threshold alone (it cannot see the vocabulary); the host
-        # can: with a large vocabulary few pairs share an id and the index wins at every threshold (3 x 100k^2 items of
-        # ~8 ids: 20k words 2.1 vs 2.2 ms at 0.7 and 4.2 vs 22 ms at 0.1; 2^17 words 1.0 vs 2.3 ms and 1.8 vs 20.9 ms)
-        use_index = True if (threshold > 0 and len(vocab) >= 8192) else None
-        return grid.jaccard_levels_grid(lt, rt, threshold, category_mode=cat_mode, index=use_index)
+
+        split = wide.wide_set_items([as_set_levels(it) for it in levels_l], [as_set_levels(it) for it in levels_r]) \
+            if _may_be_wide_sets(levels_l, levels_r) else None
+        if split is not None:
+            return split_route(split)
+        try:
+            return _fast_jaccard_levels(levels_l, levels_r, as_set_levels, threshold, cat_l, cat_r, cat_mode, dev)
+        except tables.IrregularLevels:
+            # the reference scores whatever its tokenizer yields per level (:283-299): find the items the nested layout
+            # cannot hold and route only them
+            split = wide.wide_set_items([as_set_levels(it) for it in levels_l], [as_set_levels(it) for it in levels_r],
+                                        nesting=True)
+            if split is None:
+                raise
+            return split_route(split)
     prep = lambda items: ComparableData._memoised(
         "fuzzy", items, lambda it: [score_functions.fuzzy_operand(lv) for lv in it])
     ops_l, ops_r = prep(levels_l), prep(levels_r)

@@ -682,28 +682,85 @@ def test_indel_levels_long_strings(dev, hi):
 
 
 def test_sort_hits_large(dev):
-    """nsm_sort_hits beyond the rank-sort limit (bitonic passes) against numpy's lexsort."""
+    """nsm_sort_hits beyond the single-workgroup limit (one radix sort over 128-bit keys built in place; the bitonic
+    network on a capturing stream) against numpy's lexsort: with and without the caller's hints (n_hint: geometry from
+    the live count instead of the capacity; id_limit: fewer key bits), ids with the sign bit set, many equal scores."""
     import torch
 
-    from napkon_string_matching_amd import grid
+    from napkon_string_matching_amd import _lib, grid
 
+    lib = _lib.load()
     for n, cap in ((1000, 1 << 10), (5000, 1 << 13), (8193, 1 << 14), (10_000, 1 << 20), (70_001, 70_001),
-                   (200_000, 1 << 18), (300_001, 300_001)):
+                   (200_000, 1 << 18), (300_001, 300_001), (1_500_000, 1 << 21)):
         rng = np.random.default_rng(n)
         score = rng.integers(0, 50, n).astype(np.float64) / 49.0
+        if n == 70_001:
+            score = rng.random(n)  # all different, incl. tiny values
+            score[:5] = [0.0, 1.0, 5e-324, 1e-300, 0.5]
         i = rng.integers(0, 1000, n).astype(np.int32)
         j = np.arange(n, dtype=np.int32)
         rec = np.zeros((cap, 2), dtype=np.float64)
         rec[:n, 0] = score
         rec.view(np.int32).reshape(cap, 4)[:n, 2] = i
         rec.view(np.int32).reshape(cap, 4)[:n, 3] = j
+        order = np.lexsort((j, i, -score))
+        for id_limit in (0, max(n, 1000), 1 << 31):
+            buf = grid.HitBuffer(cap, dev)
+            buf.records.copy_(torch.from_numpy(rec))
+            buf.count.fill_(n)
+            got = grid.sort_hits_device(buf, n, id_limit)
+            assert np.array_equal(got.score, score[order]), (n, cap, id_limit)
+            assert np.array_equal(got.i, i[order]) and np.array_equal(got.j, j[order])
+        # no hint at all: the geometry follows the capacity
         buf = grid.HitBuffer(cap, dev)
         buf.records.copy_(torch.from_numpy(rec))
         buf.count.fill_(n)
-        got = grid.sort_hits_device(buf, n)
-        order = np.lexsort((j, i, -score))
-        assert np.array_equal(got.score, score[order])
-        assert np.array_equal(got.i, i[order]) and np.array_equal(got.j, j[order])
+        buf.scratch = torch.empty_like(buf.records)
+        _lib.check(lib.nsm_sort_hits(buf.records.data_ptr(), buf.scratch.data_ptr(), buf.capacity, buf.count.data_ptr(), 0, 0,
+                                     torch.cuda.current_stream(dev).cuda_stream), "nsm_sort_hits")
+        host = buf.records[:n].cpu().numpy()
+        assert np.array_equal(host[:, 0], score[order]) and np.array_equal(host.view(np.int32).reshape(n, 4)[:, 2], i[order])
+    # negative ids (the sign bit is part of the order when no id_limit is promised)
+    n, cap = 20_000, 1 << 15
+    rng = np.random.default_rng(7)
+    score = rng.integers(0, 3, n).astype(np.float64) / 2.0
+    i = rng.integers(-500, 500, n).astype(np.int32)
+    j = rng.permutation(n).astype(np.int32) - 10_000
+    rec = np.zeros((cap, 2), dtype=np.float64)
+    rec[:n, 0] = score
+    rec.view(np.int32).reshape(cap, 4)[:n, 2] = i
+    rec.view(np.int32).reshape(cap, 4)[:n, 3] = j
+    buf = grid.HitBuffer(cap, dev)
+    buf.records.copy_(torch.from_numpy(rec))
+    buf.count.fill_(n)
+    got = grid.sort_hits_device(buf, n)
+    order = np.lexsort((j, i, -score))
+    assert np.array_equal(got.score, score[order]) and np.array_equal(got.i, i[order]) and np.array_equal(got.j, j[order])
+    # on a capturing stream nothing may be allocated: the bitonic network, replayed
+    n, cap = 50_000, 1 << 16
+    score = rng.integers(0, 9, n).astype(np.float64) / 8.0
+    i = rng.integers(0, 300, n).astype(np.int32)
+    j = np.arange(n, dtype=np.int32)
+    rec = np.zeros((cap, 2), dtype=np.float64)
+    rec[:n, 0] = score
+    rec.view(np.int32).reshape(cap, 4)[:n, 2] = i
+    rec.view(np.int32).reshape(cap, 4)[:n, 3] = j
+    buf = grid.HitBuffer(cap, dev)
+    buf.scratch = torch.empty_like(buf.records)
+    stream = torch.cuda.Stream(dev)
+    with torch.cuda.stream(stream):
+        buf.records.copy_(torch.from_numpy(rec))
+        buf.count.fill_(n)
+        stream.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            _lib.check(lib.nsm_sort_hits(buf.records.data_ptr(), buf.scratch.data_ptr(), buf.capacity, buf.count.data_ptr(), n, n,
+                                         stream.cuda_stream), "nsm_sort_hits")
+        g.replay()
+        torch.cuda.synchronize(dev)
+    host = buf.records[:n].cpu().numpy()
+    order = np.lexsort((j, i, -score))
+    assert np.array_equal(host[:, 0], score[order]) and np.array_equal(host.view(np.int32).reshape(n, 4)[:, 3], j[order])
 
 
 @pytest.mark.parametrize("entries,words,n_left,n_right,stride", [

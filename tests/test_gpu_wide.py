@@ -102,6 +102,65 @@ def test_levels_wide_items_through_gen_comparable():
         assert len(want) > 3
 
 
+def test_irregular_levels_through_gen_comparable():
+    """Items the suffix-nested fast layouts cannot hold (round-3 verdict: the build raised NotImplementedError for the whole
+    compare()):  (1) a CONTEXT-DEPENDENT tokenizer -- the reference re-tokenises every suffix of the compare value
+    (types/comparable_data.py:283-299: level l = tokenize(" ".join(items[-(l + 1):]))), so a tokenizer that treats the
+    START of its text specially (here: a sentence-initial capital is lower-cased, as truecasing tokenizers do) yields
+    "ca" at the level where the entry "Ca. ..." comes first and "Ca." at the deeper ones -- level l is then not
+    "level l - 1 plus more";  (2) compare_column
+    "Variable" with names of 100 characters: one level per character (:283-285, :567-574), 100 levels.  Only those items
+    leave the fast path; the result must be the oracle's gen_comparable, for both score functions."""
+    import pandas as pd
+
+    from napkon_string_matching_amd import synthetic
+    from napkon_string_matching_amd.types import comparable_data as cd
+    from napkon_string_matching_amd.types.questionnaire import Questionnaire
+    from oracle import compare as oc
+
+    def punkt_like(text: str):
+        """Whitespace split; the first word of the text is true-cased and loses a trailing period."""
+        words = text.split()
+        if words and words[0][:1].isupper():
+            words[0] = words[0].lower().rstrip(".")
+        return words
+
+    rng = random.Random(11)
+    frames = {}
+    for name, n, seed in (("hap", 70, 3), ("pop", 90, 4)):
+        frames[name] = synthetic.cohort_records(name, n, seed, vocab=50, max_entries=4, tokens_per_entry=2, min_entries=2)
+    # an entry "Ca. ..." in the middle of the value: the level at which it comes first tokenises it as "ca", the deeper
+    # levels (where text precedes it) as "Ca."
+    for name, rows in frames.items():
+        for k in range(3, len(rows), 9):
+            toks = rows[k]["Tokens"]
+            toks[len(toks) // 2] = "Ca. " + toks[len(toks) // 2]
+    frames["pop"][5]["Tokens"] = list(frames["hap"][3]["Tokens"])
+    for name, rows in frames.items():  # (2) Variable names of up to 100 characters
+        for k, row in enumerate(rows):
+            row["Variable"] = "".join(rng.choice("abcdefgh_") for _ in range(100 if k % 4 == 0 else rng.randint(3, 40)))
+    frames["pop"][8]["Variable"] = frames["hap"][0]["Variable"][:-3] + "xyz"
+    frames["pop"][16]["Variable"] = frames["hap"][4]["Variable"]
+    hap, pop = pd.DataFrame(frames["hap"]), pd.DataFrame(frames["pop"])
+    tok = cd.Tokenizer(word_tokenize=punkt_like)
+    old = cd.ComparableData.tokenizer
+    cd.ComparableData.tokenizer = tok
+    try:
+        levels = cd.ComparableData.gen_comp_value(frames["hap"][3]["Tokens"])
+        assert not all(set(a) <= set(b) for a, b in zip(levels, levels[1:])), "the tokenizer should break the nesting"
+        for func, column, thr in (("intersection_vs_union", "Tokens", 0.15), ("fuzzy_match", "Tokens", 0.4),
+                                  ("intersection_vs_union", "Variable", 0.55), ("fuzzy_match", "Variable", 0.6)):
+            kw = dict(score_func=func, compare_column=column, score_threshold=thr, left_name="hap", right_name="pop",
+                      filter_categories=column == "Tokens")
+            got = Questionnaire(hap).gen_comparable(Questionnaire(pop), None, None, **kw).dataframe()
+            want = oc.gen_comparable(hap, pop, {}, {}, tokenizer=dict(word_tokenize=punkt_like), **kw)
+            assert list(got.index) == list(want.index), (func, column)
+            assert list(got["MatchScore"]) == list(want["MatchScore"]), (func, column)
+            assert len(want) > 3, (func, column, len(want))
+    finally:
+        cd.ComparableData.tokenizer = old
+
+
 def test_any_grid_caps_fail_loudly():
     from napkon_string_matching_amd import wide
 
