@@ -89,6 +89,8 @@ def parse_args():
     ap.add_argument("--serial-sort", action="store_true",
                     help="N = 1: order the hits on the launch stream instead of a second stream (no overlap with the next step's grid)")
     ap.add_argument("--capacity", type=int, default=1 << 13)
+    ap.add_argument("--c5-stride", type=int, default=64, choices=(64, 128),
+                    help="c5 / c5w: row stride of the level-string tables (128 = the shared-tile kernel, A/B runs)")
     ap.add_argument("--split-workspace-mb", type=int, default=-1,
                     help="c5 / c5w: MiB of split-path workspace handed to nsm_indel_levels_grid (-1 = what the library asks "
                          "for, 0 = none: the single-kernel path; A/B runs)")
@@ -520,6 +522,8 @@ def run_c5(args, comm, device, steps=None, warmup=None, cpu=True, sub=False, wor
     # vectorised -- the per-item Python strings of round 1 took longer than everything else together
     t0 = time.perf_counter()
     level_codes = {nm: synthetic.c5_level_codes(c) for nm, c in cohorts.items()}
+    if args.c5_stride != 64:  # (A/B: the same strings in 128-unit rows -> the multi-word kernels)
+        level_codes = {nm: (np.pad(v[0], ((0, 0), (0, args.c5_stride - 64))),) + tuple(v[1:]) for nm, v in level_codes.items()}
     t_generate = time.perf_counter() - t0
     t0 = time.perf_counter()
     grids = []
@@ -661,6 +665,9 @@ def run_c5(args, comm, device, steps=None, warmup=None, cpu=True, sub=False, wor
         kernel_match = ("indel_levels_park_kernel<1, true>", "indel_levels_finish_kernel", "split_begin_kernel")
         kernel_label = ("nsm_indel_levels_grid, split path: indel_levels_park_kernel<1, true> (scan) + "
                         "indel_levels_finish_kernel per round (3 grid calls per step)")
+    elif threshold < 0.55:  # (csrc/indel_levels.hip: NSM_TILE_K1_BELOW -- most pairs outlive step 1 there)
+        kernel_match = "indel_levels_tile_kernel<1>"
+        kernel_label = "nsm_indel_levels_grid, shared-tile kernel: indel_levels_tile_kernel<1> (3 grid calls per step)"
     else:
         kernel_match = "indel_levels_park_kernel<1, false>"
         kernel_label = "nsm_indel_levels_grid, single-kernel path: indel_levels_park_kernel<1> (3 grid calls per step)"
@@ -699,7 +706,8 @@ def run_c5(args, comm, device, steps=None, warmup=None, cpu=True, sub=False, wor
             "level_string_generation_seconds_once": round(t_generate, 2),
             "fuzzy_grids_ms_per_step": ms_indel,
             "jaccard_grids_ms_per_step": ms_jac,
-            "fuzzy_path": "split (scan -> survivor queue in a caller-owned workspace -> finish)" if split_used else "single kernel",
+            "fuzzy_path": ("split (scan -> survivor queue in a caller-owned workspace -> finish)" if split_used else
+                           "shared-tile kernel" if threshold < 0.55 else "single kernel (scan + park + dense finish)"),
             "split_workspace_bytes": int(state["ws"].numel() * 8) if split_used else 0,
             "split_queue_overflowed": bool(m["overflow_word"]) if split_used else None,
         },
@@ -715,7 +723,7 @@ def run_c5(args, comm, device, steps=None, warmup=None, cpu=True, sub=False, wor
             "threshold": 0.7, "steps": max(1, min(steps, 2)), "ms_per_step": m7["dt"] / max(1, min(steps, 2)) * 1e3,
             "fuzzy_grids_ms_per_step": m7["ms_indel"], "jaccard_grids_ms_per_step": m7["ms_jac"],
             "hits_per_grid_this_rank": m7["counts"],
-            "fuzzy_path": "split" if state["ws"] is not None else "single kernel",
+            "fuzzy_path": "split" if state["ws"] is not None else "single kernel (scan + park + dense finish)",
             "split_queue_overflowed": bool(m7["overflow_word"]) if state["ws"] is not None else None,
         }
         state["threshold"] = float(threshold)

@@ -527,7 +527,15 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
   // addresses and 16-dword folded histograms; the shared-tile kernel instantiated for K = 1 -- with the same packed
   // two-row pass -- ran configs[4]'s fuzzy grids in 660 ms against 418 ms: per left row its H phase and double-precision
   // bookkeeping cost more than the 27-code-unit LCS they guard.)
-  const bool tile_ok = K > 1;
+  // ... at the thresholds it was tuned for.  Where MOST pairs outlive step 1 its finishing passes gather every survivor's
+  // level strings again and again (c5w -- configs[4]'s shape on word-like text -- at the cache threshold 0.5: a quarter of
+  // the same-category pairs survive step 1, 4.1 TB of HBM traffic per 500k x 500k grid, 651 ms); the shared-tile kernel
+  // keeps the tile's level strings of steps 1..3 resident in LDS and carries such rows on wave-wide: 297 ms per grid
+  // (fuzzy grids of a step 1953 -> 892 ms).  At 0.6 the picture is the reverse (572 vs 351 ms, split path 218).
+#ifndef NSM_TILE_K1_BELOW
+#define NSM_TILE_K1_BELOW 0.55
+#endif
+  const bool tile_ok = K > 1 || threshold < NSM_TILE_K1_BELOW;
   if (!(flags & NSM_FLAG_WAVE_WIDE) && tile_ok && !(flags & NSM_FLAG_PARK)) {
     // multi-word strings: shared-tile kernel (indel_levels_tile.hpp) -- the waves of a block share one right tile
     // whose level strings stay resident in LDS, and divide the left rows
@@ -622,7 +630,8 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
                        right->nlev, right->orig, right->cat, right->seg, right_strings->codes, right_strings->len, \
                        right_strings->hist, hits, hit_count, q);                                                   \
   } while (0)
-    if (K == 2) NSM_LAUNCH_TILE(2);
+    if (K == 1) NSM_LAUNCH_TILE(1);
+    else if (K == 2) NSM_LAUNCH_TILE(2);
     else if (K == 4) NSM_LAUNCH_TILE(4);
     else NSM_LAUNCH_TILE(8);
 #undef NSM_LAUNCH_TILE

@@ -52,7 +52,7 @@ def test_bench_line(workload):
     assert d["scaling"] == ("weak" if workload in ("c2", "c2low", "c3", "term") else "strong")
     if workload == "c5w":  # the cache threshold 0.5 is what the reference's flow hands to the grid; 0.7 rides along
         assert d["config"]["threshold"] == 0.5 and d["at_score_threshold"]["threshold"] == 0.7
-        assert d["at_score_threshold"]["ms_per_step"] > 0 and d["config"]["fuzzy_path"] == "single kernel"
+        assert d["at_score_threshold"]["ms_per_step"] > 0 and d["config"]["fuzzy_path"] == "shared-tile kernel"
     if workload == "c5":
         assert d["config"]["threshold"] == 0.7 and d["config"]["fuzzy_path"].startswith("split")
         assert d["config"]["split_queue_overflowed"] is False and d["config"]["split_workspace_bytes"] > 0

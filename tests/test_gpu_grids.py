@@ -568,9 +568,9 @@ def test_indel_levels_split_path_many_rounds(dev, partition):
     if not partition:
         cps = lambda c: [[[ord(ch) for ch in " ".join(level)] for level in item] for item in synthetic.c5_level_token_lists(c)]
         _same_hits(fused, native.levels(True, cps(hap), cps(pop), 0.7, None, None, mode, cap=1 << 20))
-    # expected survivors (the library's estimate): 2 % of the pairs, 1/16 of that with a partition; configs[4]'s corpus
-    # measures 0.9 % of the pairs a partition visits (~7 % of the grid)
-    expect = n_l * n_r * 0.02 * (1 / 16 if partition else 1.0)
+    # expected survivors (the library's estimate): 2 % of the pairs of table ROWS (a partitioned table has one row per item
+    # and category), 1/16 of that with a partition; configs[4]'s corpus measures 0.9 % of the pairs a partition visits
+    expect = li.n * ri.n * 0.02 * (1 / 16 if partition else 1.0)
     lib = _lib.load()
     cm = li.category_mode if li.category_mode is not None else mode
     seen_rounds = set()

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--vocab", type=int, default=20_000)
     ap.add_argument("--jaccard-flags", type=int, default=1, help="flags of nsm_jaccard_levels_grid: 1 | 4 (force index) | 8 (no index)")
     ap.add_argument("--indel-flags", type=int, default=1, help="flags of nsm_indel_levels_grid: 1 | 16 (the fused park kernel)")
+    ap.add_argument("--words", action="store_true", help="word-like tokens (synthetic.word_vocabulary) instead of t<digits>: the c5w corpus")
     ap.add_argument("--scan-stats", action="store_true", help="variant build with -DNSM_SCAN_STATS: print the scan's work counters")
     ap.add_argument("--tokens-per-entry", type=int, default=2,
                     help="words per entry; 6 makes the level strings 40..170 code units (multi-word Indel kernels)")
@@ -43,9 +44,10 @@ def main():
     lib = _lib.load()
     names = ["hap", "pop", "suep"]
     cohorts = {}
+    lex = synthetic.word_vocabulary(args.vocab) if args.words else None
     for k, nm in enumerate(names):  # pop and suep carry 1 % near-duplicates of hap items
         cohorts[nm] = synthetic.c5_cohort(args.rows, 11 + k, vocab=args.vocab, plant_from=cohorts.get("hap"),
-                                          tokens_per_entry=args.tokens_per_entry)
+                                          tokens_per_entry=args.tokens_per_entry, lex=lex)
     pairs = [("hap", "pop"), ("hap", "suep"), ("pop", "suep")]
 
     width = tables.pick_width(4 * args.tokens_per_entry)
