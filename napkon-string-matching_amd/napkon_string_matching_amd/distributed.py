@@ -5,8 +5,9 @@ The grid shards naturally -- every pair's score depends on item i and item j onl
 rows are split into contiguous blocks, the right side is replicated and there is no collective on
 the data path.  The only exchange is at the end: an all-gatherv of the above-threshold
 ``(score, i, j)`` records.  RCCL has no native gatherv: the hit buffer carries its counter in a trailing
-record, so ONE all-gather of the max-padded storage moves records and counts (``all_gather_storage``; ``bench.py``
-times that collective on the device-resident buffer, the product adds host-side packing around it).  Volumes are tiny next to xGMI bandwidth (16 B per hit).
+record, so ONE all-gather of the max-padded storage moves records and counts (``all_gather_storage``: the same
+function, on device-resident buffers, for ``bench.py`` and for the product's ``gen_comparable``).  Volumes are tiny next
+to xGMI bandwidth (16 B per hit).
 """
 from __future__ import annotations
 
@@ -59,11 +60,11 @@ def all_gather_storage(storage: torch.Tensor, out: Optional[torch.Tensor] = None
     device, allocated when omitted); with gloo the buffer is staged through host memory.  Returns
     ``(out, work)``; ``work`` is the handle of an ``async_op`` RCCL gather, else None.
 
-    Both callers move the same wire format through this function, but they do not do the same work around it:
-    ``bench.py`` gathers the DEVICE-resident ``HitBuffer.storage`` at a fixed capacity, asynchronously, overlapped
-    with the next grid; ``ComparableData.gen_comparable`` (``all_gather_hits`` below) starts from hits it has already
-    filtered on the host (blacklist), agrees on a capacity with one MAX all-reduce, packs, copies to the device,
-    gathers and copies back.  The exchange cost bench.py reports is the collective's, not the product path's."""
+    Callers: ``bench.py`` gathers the DEVICE-resident ``HitBuffer.storage`` at a fixed capacity, asynchronously,
+    overlapped with the next grid; ``ComparableData.gen_comparable`` gathers its device-resident hits the same way
+    (``all_gather_pending``: capacity agreed with one MAX all-reduce) whenever nothing has to be filtered on the host,
+    and falls back to ``all_gather_hits`` (host-filtered hits: pack, copy to the device, gather, copy back) when a
+    blacklist or a host-side category predicate has to look at the hits first."""
     import torch.distributed as dist
 
     size = dist.get_world_size(group)
@@ -77,6 +78,60 @@ def all_gather_storage(storage: torch.Tensor, out: Optional[torch.Tensor] = None
     dist.all_gather_into_tensor(host, storage.detach().cpu().contiguous(), group=group)
     out.copy_(host.view_as(out))
     return out, None
+
+
+def agree_all(flag: bool) -> bool:
+    """True iff ``flag`` is true on EVERY rank (one MIN all-reduce): decisions that change which collectives follow must
+    be taken by all ranks together."""
+    import torch.distributed as dist
+
+    rank, size = world()
+    if size == 1:
+        return bool(flag)
+    on_device = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_device else torch.device("cpu")
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
+def all_gather_pending(pending, n_left: int, nlev_left: np.ndarray, nlev_right: np.ndarray, world_size: int):
+    """The exchange of a sharded ``gen_comparable`` whose hits are still in their DEVICE buffers (``grid.PendingHits``;
+    a rank whose shard had nothing to score passes None): one MAX all-reduce agrees on the capacity, every rank's
+    ``capacity + 1`` records go through ONE all-gather (``all_gather_storage``: device to device under RCCL), and only the
+    gathered result is copied to the host.  The records carry row ids relative to each rank's own sub-grid (its left
+    shard's items with at least one level x the right items with at least one level); every rank knows every shard's
+    bounds, so the mapping back to frame positions is done here.  Returns (score, i, j) in the canonical order."""
+    import torch.distributed as dist
+
+    on_device = dist.get_backend() == "nccl"
+    dev = pending.buf.records.device if pending is not None else (
+        torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu"))
+    red = dev if on_device else torch.device("cpu")
+    cap = torch.tensor([pending.n if pending is not None else 0], dtype=torch.int64, device=red)
+    dist.all_reduce(cap, op=dist.ReduceOp.MAX)
+    capacity = max(1, int(cap.item()))
+    if pending is not None:
+        storage = pending.storage(capacity)
+    else:
+        storage = torch.zeros((capacity + 1, 2), dtype=torch.float64, device=dev)
+    gathered, _ = all_gather_storage(storage)
+    g = gathered.detach().cpu().numpy()
+    counts = g.view(np.int64).reshape(g.shape[0], capacity + 1, 2)[:, capacity, 0]
+    ij = g.view(np.int32).reshape(g.shape[0], capacity + 1, 4)
+    keep_r = np.flatnonzero(np.asarray(nlev_right) > 0)
+    has_level = np.asarray(nlev_left) > 0
+    parts_s, parts_i, parts_j = [], [], []
+    for r in range(world_size):
+        lo, hi = shard_bounds(n_left, r, world_size)
+        keep_l = lo + np.flatnonzero(has_level[lo:hi])
+        n = int(min(max(counts[r], 0), capacity))
+        parts_s.append(g[r, :n, 0])
+        parts_i.append(keep_l[ij[r, :n, 2]] if n else np.zeros(0, np.int64))
+        parts_j.append(keep_r[ij[r, :n, 3]] if n else np.zeros(0, np.int64))
+    s, gi, gj = np.concatenate(parts_s), np.concatenate(parts_i).astype(np.int64), np.concatenate(parts_j).astype(np.int64)
+    order = np.lexsort((gj, gi, -s))
+    return s[order], gi[order], gj[order]
 
 
 def pack_hits(score: np.ndarray, i: np.ndarray, j: np.ndarray, capacity: int) -> torch.Tensor:

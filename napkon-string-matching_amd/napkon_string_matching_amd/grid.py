@@ -91,10 +91,30 @@ def sort_hits_device(buf: HitBuffer, n: int, id_limit: int = 0) -> Hits:
     return Hits(host[:, 0].copy(), ij[:, 2].copy(), ij[:, 3].copy())
 
 
+class PendingHits:
+    """The hits of a finished grid still in their device buffer (``run_grid(..., defer=True)``): ``finish()`` orders them
+    and copies them to the host as always; ``storage(capacity)`` is the wire format of the multi-GPU exchange
+    (``distributed.all_gather_storage``) at a capacity the ranks agreed on -- ``capacity`` records and the counter record,
+    built on the device, so a sharded ``compare()`` moves its hits GPU -> RCCL -> GPU without a detour through the host."""
+
+    def __init__(self, buf: HitBuffer, n: int, id_limit: int) -> None:
+        self.buf, self.n, self.id_limit = buf, int(n), int(id_limit)
+
+    def finish(self) -> Hits:
+        return sort_hits_device(self.buf, self.n, self.id_limit)
+
+    def storage(self, capacity: int) -> torch.Tensor:
+        out = torch.zeros((int(capacity) + 1, 2), dtype=torch.float64, device=self.buf.records.device)
+        out[: self.n] = self.buf.records[: self.n]
+        out[int(capacity):].view(torch.int64).view(-1)[0] = self.n
+        return out
+
+
 def run_grid(launch: Callable[[HitBuffer, int], int], device, capacity: Optional[int], what: str,
-             id_limit: int = 0) -> Hits:
+             id_limit: int = 0, defer: bool = False):
     """Run ``launch`` with a hit buffer, growing it once if the counter overflowed.  ``id_limit``: an upper bound of
-    the row ids the grid reports (the larger side's item count), 0 = unknown."""
+    the row ids the grid reports (the larger side's item count), 0 = unknown.  ``defer``: return the hits in their
+    device buffer (``PendingHits``) instead of ordering and copying them."""
     dev = _require_gpu(device)
     buf = HitBuffer(capacity or DEFAULT_CAPACITY, dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -103,7 +123,7 @@ def run_grid(launch: Callable[[HitBuffer, int], int], device, capacity: Optional
         _lib.check(launch(buf, stream), what)
         n = int(buf.count.item())  # synchronises the stream
         if n <= buf.capacity:
-            return sort_hits_device(buf, n, id_limit)
+            return PendingHits(buf, n, id_limit) if defer else sort_hits_device(buf, n, id_limit)
         buf = HitBuffer(n, dev)
     raise _lib.NsmLibraryError(f"{what}: hit count changed between two identical launches")
 
@@ -156,7 +176,7 @@ def indel_raw_grid(
 # ------------------------------------------------------------------------------- levels grids
 def jaccard_levels_grid(
     left: SetTable, right: SetTable, threshold: float, category_mode: int = _lib.CAT_NONE, prune: bool = True,
-    capacity: Optional[int] = None, index: Optional[bool] = None,
+    capacity: Optional[int] = None, index: Optional[bool] = None, defer: bool = False,
 ) -> Hits:
     """``compare_terms`` with ``intersection_vs_union`` over suffix-nested levels.
     ``index``: None = the library decides (inverted-index candidates at low thresholds), True / False = force."""
@@ -176,13 +196,13 @@ def jaccard_levels_grid(
             buf.count.data_ptr(), stream,
         )
 
-    return run_grid(launch, left.ids.device, capacity, "nsm_jaccard_levels_grid")
+    return run_grid(launch, left.ids.device, capacity, "nsm_jaccard_levels_grid", defer=defer)
 
 
 def indel_levels_grid(
     left: LevelItems, left_strings: StrTable, right: LevelItems, right_strings: StrTable, threshold: float,
     category_mode: int = _lib.CAT_NONE, prune: bool = True, capacity: Optional[int] = None, wave_wide: bool = False,
-    park: bool = False, workspace: Optional[int] = None, return_overflow: Optional[list] = None,
+    park: bool = False, workspace: Optional[int] = None, return_overflow: Optional[list] = None, defer: bool = False,
 ) -> Hits:
     """``compare_terms`` with ``fuzzy_match`` over per-level strings.  ``wave_wide`` selects the kernel
     without block-cooperative parking, ``park`` the round-2 kernel for multi-word strings (same hits; A/B runs
@@ -208,7 +228,7 @@ def indel_levels_grid(
             buf.count.data_ptr(), ws.data_ptr() if ws is not None else 0, ws.numel() * 8 if ws is not None else 0, stream,
         )
 
-    hits = run_grid(launch, dev, capacity, "nsm_indel_levels_grid")  # (returns after the stream has been synchronised)
+    hits = run_grid(launch, dev, capacity, "nsm_indel_levels_grid", defer=defer)  # (returns after the stream has been synchronised)
     if ws is not None and return_overflow is not None:
         return_overflow.append(int(ws[1].item()) & 0xFFFFFFFF)
     return hits

@@ -677,6 +677,11 @@ class StrTable:
             if "code unit outside the alphabet" in str(exc):
                 raise ValueError("code unit outside the alphabet") from exc
             raise
+        # the spare row is defined memory: an empty string (length 0, pad codes, empty histogram)
+        t.codes[n:].fill_(alphabet)
+        t.len[n:].zero_()
+        t.orig[n:].zero_()
+        t.hist[n:].zero_()
         t.codes, t.len, t.orig, t.hist = t.codes[:n], t.len[:n], t.orig[:n], t.hist[:n]
         return t
 

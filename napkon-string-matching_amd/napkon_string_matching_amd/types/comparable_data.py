@@ -201,9 +201,20 @@ def _read_cache_collectively(cache_file: Path) -> Comparable:
     rank, size = distributed.world()
     if size == 1:
         return Comparable.read_json(cache_file)
-    text = cache_file.read_text(encoding="utf-8") if rank == 0 else None
-    text = distributed.broadcast_object(text)
-    return Comparable(data=json.loads(text))
+    # rank 0 may fail (unreadable or corrupt file): it must still take part in the broadcast, or the other ranks wait
+    # for it forever -- the failure travels as the payload and every rank raises it (round-3 advice)
+    box = None
+    if rank == 0:
+        try:
+            text = cache_file.read_text(encoding="utf-8")
+            json.loads(text)
+            box = (True, text)
+        except Exception as exc:  # noqa: BLE001 -- re-raised on every rank below
+            box = (False, f"{type(exc).__name__}: {exc}")
+    ok, payload = distributed.broadcast_object(box)
+    if not ok:
+        raise RuntimeError(f"compare cache {cache_file} could not be read on rank 0: {payload}")
+    return Comparable(data=json.loads(payload))
 
 
 class ComparableData:
@@ -378,13 +389,22 @@ class ComparableData:
                 identifier_column_right=identifier_column_right,
                 **kwargs,
             )
-            if cache_file is not None and distributed.world()[0] == 0:
-                # every rank of a sharded run holds the full result: rank 0 writes it (atomically, see write_json)
-                cache_file.parent.mkdir(parents=True, exist_ok=True)
-                logger.info("write cache to file")
-                result.write_json(cache_file)
             if cache_file is not None:
-                distributed.barrier()  # nobody returns (and calls compare again) before the file is in place
+                # every rank of a sharded run holds the full result: rank 0 writes it (atomically, see write_json); its
+                # verdict is broadcast, which also is the barrier: nobody returns (and calls compare again) before the
+                # file is in place, and a failed write (disk full) raises on every rank instead of leaving them waiting
+                error = None
+                if distributed.world()[0] == 0:
+                    try:
+                        cache_file.parent.mkdir(parents=True, exist_ok=True)
+                        logger.info("write cache to file")
+                        result.write_json(cache_file)
+                    except Exception as exc:  # noqa: BLE001 -- re-raised on every rank below
+                        error = f"{type(exc).__name__}: {exc}"
+                if distributed.world()[1] > 1:
+                    error = distributed.broadcast_object(error)
+                if error is not None:
+                    raise RuntimeError(f"compare cache {cache_file} could not be written on rank 0: {error}")
         result = result[result.match_score >= score_threshold]
         logger.info("got %i filtered entries", len(result))
         result.sort_by_score()
@@ -484,6 +504,8 @@ class ComparableData:
             keep_l = keep_l[(keep_l >= row_lo) & (keep_l < row_hi)]
             extra_hits = [p for p in extra_hits if row_lo <= p[0] < row_hi]
         logger.info("calculate score")
+        host_filter = bool(banned) or (cats is not None and not cats.on_device)
+        pending = None
         if keep_l.size and keep_r.size:
             on_device = cats is not None and cats.on_device
             hits = _levels_grid(
@@ -494,28 +516,47 @@ class ComparableData:
                 cats.left_mask[keep_l] if on_device else None,
                 cats.right_mask[keep_r] if on_device else None,
                 cats.mode if on_device else _lib.CAT_NONE,
+                defer=world_size > 1 and not host_filter,
             )
-            hi, hj, hs = keep_l[hits.i], keep_r[hits.j], hits.score
+            if isinstance(hits, grid.PendingHits):
+                pending = hits
+        extra = bool(extra_hits) and 0.0 >= score_threshold
+        if world_size > 1:
+            # The one exchange step: all-gatherv of the hits.  When every rank's hits sit in ONE device buffer and nothing
+            # has to be filtered on the host (no blacklist, the category predicate ran in the kernel, no zero-level pairs)
+            # the buffers go GPU -> all-gather -> GPU at a capacity agreed with one MAX all-reduce; otherwise the ranks
+            # exchange what they have filtered on the host.  The choice is collective (one MIN all-reduce).
+            nothing_to_score = not (keep_l.size and keep_r.size)  # (this rank's shard: it then contributes an empty buffer)
+            direct = distributed.agree_all((pending is not None or nothing_to_score) and not extra and not host_filter)
         else:
-            hi, hj, hs = np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.float64)
-        if extra_hits and 0.0 >= score_threshold:
-            ei = np.array([p[0] for p in extra_hits], dtype=np.int64)
-            ej = np.array([p[1] for p in extra_hits], dtype=np.int64)
-            hi, hj, hs = np.concatenate([hi, ei]), np.concatenate([hj, ej]), np.concatenate([hs, np.zeros(len(ei))])
+            direct = False
+        if direct:
+            hs, hi, hj = distributed.all_gather_pending(pending, n_l, nlev_l, nlev_r, world_size)
+        else:
+            if pending is not None:
+                hits = pending.finish()
+            if keep_l.size and keep_r.size:
+                hi, hj, hs = keep_l[hits.i], keep_r[hits.j], hits.score
+            else:
+                hi, hj, hs = np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.float64)
+            if extra:
+                ei = np.array([p[0] for p in extra_hits], dtype=np.int64)
+                ej = np.array([p[1] for p in extra_hits], dtype=np.int64)
+                hi, hj, hs = np.concatenate([hi, ei]), np.concatenate([hj, ej]), np.concatenate([hs, np.zeros(len(ei))])
 
-        # ---- per hit: blacklist (and categories when they could not go to the device)
-        if len(hs) and (banned or (cats is not None and not cats.on_device)):
-            ok = np.fromiter(
-                (
-                    (int(a), int(b)) not in banned and (cats is None or cats.on_device or cats.match(int(a), int(b)))
-                    for a, b in zip(hi, hj)
-                ),
-                dtype=bool, count=len(hs),
-            )
-            hi, hj, hs = hi[ok], hj[ok], hs[ok]
+            # ---- per hit: blacklist (and categories when they could not go to the device)
+            if len(hs) and host_filter:
+                ok = np.fromiter(
+                    (
+                        (int(a), int(b)) not in banned and (cats is None or cats.on_device or cats.match(int(a), int(b)))
+                        for a, b in zip(hi, hj)
+                    ),
+                    dtype=bool, count=len(hs),
+                )
+                hi, hj, hs = hi[ok], hj[ok], hs[ok]
 
-        if world_size > 1:  # the one exchange step: all-gatherv of the hits
-            hs, hi, hj = distributed.all_gather_hits(hs, hi, hj)
+            if world_size > 1:  # (host-filtered hits: packed, copied to the device, gathered, copied back)
+                hs, hi, hj = distributed.all_gather_hits(hs, hi, hj)
 
         # ---- output frame in the reference's row order (pair label ascending)
         label = hi.astype(np.int64) * n_r + hj.astype(np.int64)
@@ -639,7 +680,7 @@ def _may_be_wide_sets(*sides) -> bool:
     return any(size(it[-1]) > 64 for items in sides for it in items if len(it))
 
 
-def _fast_jaccard_levels(levels_l, levels_r, as_set_levels, threshold, cat_l, cat_r, cat_mode, dev) -> grid.Hits:
+def _fast_jaccard_levels(levels_l, levels_r, as_set_levels, threshold, cat_l, cat_r, cat_mode, dev, defer=False):
     """The suffix-nested fast layout of both sides + ``nsm_jaccard_levels_grid``; raises ``tables.IrregularLevels`` when an
     item does not fit it."""
     part = tables.partition_allowed(cat_mode, cat_l, cat_r)
@@ -673,11 +714,14 @@ def _fast_jaccard_levels(levels_l, levels_r, as_set_levels, threshold, cat_l, ca
     # can: with a large vocabulary few pairs share an id and the index wins at every threshold (3 x 100k^2 items of
     # ~8 ids: 20k words 2.1 vs 2.2 ms at 0.7 and 4.2 vs 22 ms at 0.1; 2^17 words 1.0 vs 2.3 ms and 1.8 vs 20.9 ms)
     use_index = True if (threshold > 0 and len(vocab) >= 8192) else None
-    return grid.jaccard_levels_grid(lt, rt, threshold, category_mode=cat_mode, index=use_index)
+    return grid.jaccard_levels_grid(lt, rt, threshold, category_mode=cat_mode, index=use_index, defer=defer)
 
 
-def _levels_grid(plugin, levels_l, levels_r, threshold, cat_l, cat_r, cat_mode=_lib.CAT_NONE) -> grid.Hits:
-    """Encode both sides' levels for ``plugin`` and run the levels grid on the current device."""
+def _levels_grid(plugin, levels_l, levels_r, threshold, cat_l, cat_r, cat_mode=_lib.CAT_NONE, defer: bool = False):
+    """Encode both sides' levels for ``plugin`` and run the levels grid on the current device.  ``defer``: when the
+    whole grid goes through ONE fast kernel call, return its hits still on the device (``grid.PendingHits``: the sharded
+    ``gen_comparable`` exchanges them without a host detour); grids that are split (wide / irregular items) return
+    ``grid.Hits`` as always."""
     import torch
 
     if not torch.cuda.is_available():
@@ -704,7 +748,7 @@ def _levels_grid(plugin, levels_l, levels_r, threshold, cat_l, cat_r, cat_mode=_
         if split is not None:
             return split_route(split)
         try:
-            return _fast_jaccard_levels(levels_l, levels_r, as_set_levels, threshold, cat_l, cat_r, cat_mode, dev)
+            return _fast_jaccard_levels(levels_l, levels_r, as_set_levels, threshold, cat_l, cat_r, cat_mode, dev, defer)
         except tables.IrregularLevels:
             # the reference scores whatever its tokenizer yields per level (:283-299): find the items the nested layout
             # cannot hold and route only them
@@ -727,4 +771,4 @@ def _levels_grid(plugin, levels_l, levels_r, threshold, cat_l, cat_r, cat_mode=_
                                                      cat_mode, device=dev)
         return wide.split_grid(split[0], split[1], fast, general)
     li, ls, ri, rs = tables.encode_level_strings(ops_l, ops_r, dev, cat_l, cat_r, cat_mode)
-    return grid.indel_levels_grid(li, ls, ri, rs, threshold, category_mode=cat_mode)
+    return grid.indel_levels_grid(li, ls, ri, rs, threshold, category_mode=cat_mode, defer=defer)

@@ -204,6 +204,39 @@ assert np.array_equal(s, score[order]) and np.array_equal(gi, i[order]) and np.a
 # an empty contribution from one rank must work too
 s2, _, _ = all_gather_hits(score[:0] if rank else score, i[:0] if rank else i, j[:0] if rank else j)
 assert len(s2) == n
+# the device-resident form of the same exchange (gen_comparable without a blacklist): every rank hands over its hit
+# BUFFER with ids relative to its own sub-grid (left shard's items that have levels x right items that have levels)
+from napkon_string_matching_amd import grid
+from napkon_string_matching_amd.distributed import agree_all, all_gather_pending
+assert agree_all(True) is True and agree_all(rank == 0) is False
+n_left, n_right = 23, 9
+nlev_l = np.array([0 if k % 5 == 2 else 3 for k in range(n_left)])
+nlev_r = np.array([0 if k == 4 else 2 for k in range(n_right)])
+keep_r = np.flatnonzero(nlev_r > 0)
+want = []
+pending = None
+for r in range(size):
+    lo, hi = shard_bounds(n_left, r, size)
+    keep_l = lo + np.flatnonzero(nlev_l[lo:hi] > 0)
+    rr = np.random.default_rng(100 + r)
+    m = 0 if r == 1 and size > 1 and False else 17 + r
+    li, lj = rr.integers(0, len(keep_l), m), rr.integers(0, len(keep_r), m)
+    sc = rr.integers(0, 4, m) / 3.0
+    want += [(float(a), int(keep_l[b]), int(keep_r[c])) for a, b, c in zip(sc, li, lj)]
+    if r == rank:
+        buf = grid.HitBuffer(64, "cpu")
+        rec = buf.records.numpy()
+        rec[:m, 0] = sc
+        rec.view(np.int32).reshape(-1, 4)[:m, 2] = li
+        rec.view(np.int32).reshape(-1, 4)[:m, 3] = lj
+        buf.count.fill_(m)
+        pending = grid.PendingHits(buf, m, 0)
+s, gi, gj = all_gather_pending(pending, n_left, nlev_l, nlev_r, size)
+want.sort(key=lambda t: (-t[0], t[1], t[2]))
+assert [(float(a), int(b), int(c)) for a, b, c in zip(s, gi, gj)] == want, rank
+# a rank without anything to score contributes an empty buffer
+s3, _, _ = all_gather_pending(pending if rank == 0 else None, n_left, nlev_l, nlev_r, size)
+assert len(s3) == 17
 dist.destroy_process_group()
 print("rank", rank, "ok")
 '''

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--jaccard-flags", type=int, default=1, help="flags of nsm_jaccard_levels_grid: 1 | 4 (force index) | 8 (no index)")
     ap.add_argument("--indel-flags", type=int, default=1, help="flags of nsm_indel_levels_grid: 1 | 16 (the fused park kernel)")
     ap.add_argument("--words", action="store_true", help="word-like tokens (synthetic.word_vocabulary) instead of t<digits>: the c5w corpus")
+    ap.add_argument("--tile-stats", action="store_true", help="variant build with -DNSM_TILE_STATS: print the shared-tile kernel's work counters")
     ap.add_argument("--scan-stats", action="store_true", help="variant build with -DNSM_SCAN_STATS: print the scan's work counters")
     ap.add_argument("--tokens-per-entry", type=int, default=2,
                     help="words per entry; 6 makes the level strings 40..170 code units (multi-word Indel kernels)")
@@ -122,6 +123,18 @@ def main():
         out["scan_stats_first_grid"] = dict(zip(
             ["rows_visited", "pairs_in_category", "pairs_alive_after_H", "rows_scored", "pairs_alive_after_step1",
              "two_row_passes", "one_row_passes"], [int(v) for v in st]))
+
+    if args.tile_stats:
+        import ctypes
+
+        st = (ctypes.c_ulonglong * 16)()
+        lib.nsm_debug_tile_stats(st)  # reset
+        run_indel(*pairs[0])
+        lib.nsm_debug_tile_stats(st)
+        out["tile_stats_first_grid"] = dict(zip(
+            ["batches", "step1 two-row passes", "step1 two-row iterations", "step1 one-row passes", "step1 one-row iterations",
+             "later two-row passes", "later two-row iterations", "later one-row passes", "later one-row iterations",
+             "dense calls", "dense LCS passes", "dense iterations", "parked pairs", "table builds"], [int(v) for v in st]))
 
     if args.check:
         from oracle import native
