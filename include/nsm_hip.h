@@ -84,17 +84,19 @@ typedef struct nsm_hit {
  *                                  is the signature word (same layout as sig) of the row's first
  *                                  plen[min(1,L-1)] ids, i.e. of the set every step of compare_terms contains
  *                                  (one s_load per 2 rows)
- *   -- global inverted index (RAW mode, optional: NULL = none).  nsm_build_set_table fills both columns when the caller
- *      provides them; nsm_jaccard_raw_grid uses the RIGHT table's index to generate candidate pairs instead of visiting
- *      all N x M (prefix filter: with the ids of every row in one global order -- ascending id -- two sets can only reach
- *      the threshold if they share an id among their first few; a host that numbers its tokens by INCREASING corpus
- *      frequency gets the shortest posting lists, any numbering is correct) --
+ *   -- global inverted index (optional: NULL = none).  nsm_build_set_table fills both columns when the caller provides
+ *      them; the Jaccard grids use the RIGHT table's index to generate candidate pairs instead of visiting all N x M.
+ *      RAW: prefix filter -- with the ids of every row in one global order (ascending id) two sets can only reach the
+ *      threshold if they share an id among their first few; a host that numbers its tokens by INCREASING corpus frequency
+ *      gets the shortest posting lists, any numbering is correct.  Levels: a pair scores above 0 only if it shares an id;
+ *      a partitioned table keys its postings by (category segment, id) -- key = seg * vocab + id, 64 vocab keys -- so a
+ *      probe only meets rows of its own category --
  *   post        device uint64[n * width]    one entry per (row, id) sorted by (id, position p of the id in its row);
  *                                           entry = row | p << 32 | cnt << 40; the unused tail is zero
- *   post_start  device int32 [5 * vocab + 1] entries of id t with p < 1 / 2 / 4 / 8 / any are
- *                                           [post_start[5 t], post_start[5 t + 1 / 2 / 3 / 4 / 5])
+ *   post_start  device int32 [5 * keys + 1]  (keys = vocab, or 64 vocab for a partitioned levels table) entries of key t
+ *                                           with p < 1 / 2 / 4 / 8 / any are [post_start[5 t], post_start[5 t + 1 / 2 / 3 / 4 / 5])
  *   vocab       every id of the table is < vocab (checked by the builder)
- *   post_sq     HOST values written by the builder: post_sq[c] = sum over ids of (number of its entries in
+ *   post_sq     HOST values written by the builder: post_sq[c] = sum over keys of (number of its entries in
  *               [post_start[5 t], post_start[5 t + c + 1]))^2 -- what the grid estimates its candidate count from
  */
 typedef struct nsm_set_table {

@@ -289,8 +289,9 @@ __global__ void set_gather_kernel(const int32_t* __restrict__ perm, const int32_
 // (unused slots: all ones, sorted last), one radix sort, then the offsets: 5 boundaries per id (positions < 1, 2, 4, 8, any).
 __device__ __forceinline__ int post_class(int pos) { return pos < 1 ? 0 : pos < 2 ? 1 : pos < 4 ? 2 : pos < 8 ? 3 : 4; }
 
-__global__ void post_keys_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ cnt, int rows, int width, int vocab,
-                                 unsigned long long* __restrict__ keys, unsigned long long* __restrict__ vals, Status* st) {
+__global__ void post_keys_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ cnt, const int32_t* __restrict__ seg,
+                                 int rows, int width, int vocab, unsigned long long* __restrict__ keys,
+                                 unsigned long long* __restrict__ vals, Status* st) {
   const long long s = static_cast<long long>(blockIdx.x) * kThreads + threadIdx.x;
   if (s >= static_cast<long long>(rows) * width) return;
   const int r = static_cast<int>(s / width), k = static_cast<int>(s % width);
@@ -300,7 +301,10 @@ __global__ void post_keys_kernel(const int32_t* __restrict__ ids, const int32_t*
     const int32_t id = ids[s];
     if (id >= vocab) atomicMax(&st->err, static_cast<int>(kErrBadVocab));
     else {
-      key = (static_cast<unsigned long long>(static_cast<uint32_t>(id)) << 8) | static_cast<unsigned long long>(k);
+      // (a partitioned levels table: one key space per category segment, so a probe only meets rows of its own category)
+      const unsigned long long tok = (seg ? static_cast<unsigned long long>(seg[r]) * static_cast<unsigned long long>(vocab) : 0ull) +
+                                     static_cast<unsigned long long>(static_cast<uint32_t>(id));
+      key = (tok << 8) | static_cast<unsigned long long>(k);
       val = static_cast<unsigned long long>(static_cast<uint32_t>(r)) | (static_cast<unsigned long long>(k) << 32) |
             (static_cast<unsigned long long>(c) << 40);
     }
@@ -586,8 +590,11 @@ extern "C" int nsm_build_set_table(const int32_t* ids_in, int32_t n, int32_t wid
   unsigned long long* d_sq = nullptr;
   for (int c = 0; c < 5; ++c) out->post_sq[c] = 0;
   if (out->post || out->post_start) {
-    if (levels || !out->post || !out->post_start || out->vocab < 1 || out->vocab > (1 << 25)) {
-      set_error("%s: the global inverted index needs a RAW table, both the post and post_start columns and vocab in [1, 2^25]", who);
+    // key space: ids, times 64 category segments for a partitioned levels table
+    const long long n_keys = static_cast<long long>(out->vocab) * (partition ? 64 : 1);
+    if (!out->post || !out->post_start || out->vocab < 1 || n_keys > (1ll << 25)) {
+      set_error("%s: the global inverted index needs both the post and post_start columns and 1 <= vocab (x 64 with a category "
+                "partition) <= 2^25", who);
       return NSM_E_BADARG;
     }
     const long long slots = static_cast<long long>(rows) * width;
@@ -598,13 +605,13 @@ extern "C" int nsm_build_set_table(const int32_t* ids_in, int32_t n, int32_t wid
     if (sc.failed) return hip_status(hipErrorOutOfMemory, "builder scratch");
     (void)hipMemsetAsync(d_sq, 0, 5 * sizeof(unsigned long long), stream);
     int bits = 1;
-    while ((1ll << bits) < out->vocab) ++bits;
+    while ((1ll << bits) < n_keys) ++bits;
     bits += 8;
     const unsigned long long key_mask = (1ull << bits) - 1ull;
     unsigned long long* post = const_cast<unsigned long long*>(reinterpret_cast<const unsigned long long*>(out->post));
     if (slots > 0) {
-      hipLaunchKernelGGL(post_keys_kernel, blocks_for(slots), dim3(kThreads), 0, stream, out->ids, out->cnt, rows, width, out->vocab,
-                         keys, vals, d_status);
+      hipLaunchKernelGGL(post_keys_kernel, blocks_for(slots), dim3(kThreads), 0, stream, out->ids, out->cnt,
+                         partition ? out->seg : static_cast<const int32_t*>(nullptr), rows, width, out->vocab, keys, vals, d_status);
       size_t bytes = 0;
       hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, keys, keys_sorted, vals, post, static_cast<size_t>(slots), 0u,
                                                static_cast<unsigned>(bits), stream);
@@ -615,9 +622,10 @@ extern "C" int nsm_build_set_table(const int32_t* ids_in, int32_t n, int32_t wid
                                     static_cast<unsigned>(bits), stream);
       if (e != hipSuccess) return hip_status(e, "radix_sort_pairs (postings)");
     }
-    hipLaunchKernelGGL(post_bounds_kernel, blocks_for(slots + 1), dim3(kThreads), 0, stream, keys_sorted, slots, out->vocab, key_mask,
-                       const_cast<int32_t*>(out->post_start), post);
-    hipLaunchKernelGGL(post_stats_kernel, blocks_for(out->vocab), dim3(kThreads), 0, stream, out->post_start, out->vocab, d_sq);
+    hipLaunchKernelGGL(post_bounds_kernel, blocks_for(slots + 1), dim3(kThreads), 0, stream, keys_sorted, slots,
+                       static_cast<int>(n_keys), key_mask, const_cast<int32_t*>(out->post_start), post);
+    hipLaunchKernelGGL(post_stats_kernel, blocks_for(n_keys), dim3(kThreads), 0, stream, out->post_start, static_cast<int>(n_keys),
+                       d_sq);
   }
   out->n = rows;
   if (d_sq) {

@@ -179,12 +179,17 @@ def jaccard_levels_grid(
     capacity: Optional[int] = None, index: Optional[bool] = None, defer: bool = False,
 ) -> Hits:
     """``compare_terms`` with ``intersection_vs_union`` over suffix-nested levels.
-    ``index``: None = the library decides (inverted-index candidates at low thresholds), True / False = force."""
+    ``index``: None = the library decides (candidates from the right table's global inverted index where its posting
+    statistics say they are few, from a per-tile index at low thresholds, else the filter kernel over all pairs);
+    True = force an index (the global one when the right table carries it), "tile" = force the per-tile index,
+    False = never an index."""
     if left.nlev is None or right.nlev is None:
         raise ValueError("levels grid needs tables built with SetTable.from_levels")
     lib = _lib.load()
     ls, rs = left.struct(), right.struct()
     flags = (_lib.FLAG_PRUNE if prune else 0) | (0 if index is None else (_lib.FLAG_INDEX if index else _lib.FLAG_NO_INDEX))
+    if index == "tile":
+        flags |= _lib.FLAG_TILE_INDEX
     if (left.seg is None) != (right.seg is None) or left.category_mode != right.category_mode:
         raise ValueError("both sides must be encoded alike: same category_mode and partition (tables.partition_allowed)")
     if left.category_mode is not None:  # the encoder may have rewritten the predicate (partition)

@@ -29,7 +29,7 @@ from . import _lib
 WIDTHS = (16, 32, 64)
 STRIDES = (64, 128, 256, 512)  # code units per string row: 1, 2, 4 or 8 words of the bit-parallel LCS
 MAX_LEVELS = 64
-MAX_INDEX_VOCAB = 1 << 22  # largest id + 1 for which a RAW right table gets its global inverted index (20 bytes of offsets per id)
+MAX_INDEX_VOCAB = 1 << 23  # most index keys (ids; x 64 with a category partition) for which a right table gets its global inverted index by default (20 bytes of offsets per key)
 LEFT_PAD, RIGHT_PAD = -1, -2
 EMPTY_CATEGORY_BIT = 63  # stands for "no category at all" when empty-vs-empty counts as a match
 _GOLDEN = np.uint32(0x9E3779B1)
@@ -41,15 +41,19 @@ class IrregularLevels(NotImplementedError):
     host routes such items -- and only them -- through the general kernels (wide.py)."""
 
 
-def inverted_index(ids: np.ndarray, cnt: np.ndarray, vocab: int):
-    """The global inverted index of a RAW table (include/nsm_hip.h: post / post_start / post_sq), the numpy way --
-    what ``nsm_build_set_table`` builds on the GPU, byte for byte.  ``ids`` [n][W] ascending per row, ``cnt`` [n]."""
+def inverted_index(ids: np.ndarray, cnt: np.ndarray, vocab: int, seg: Optional[np.ndarray] = None):
+    """The global inverted index of a set table (include/nsm_hip.h: post / post_start / post_sq), the numpy way --
+    what ``nsm_build_set_table`` builds on the GPU, byte for byte.  ``ids`` [n][W] (RAW: ascending per row), ``cnt`` [n];
+    ``seg`` [n]: a partitioned levels table keys its postings by (category segment, id)."""
     n, width = ids.shape
     valid = np.arange(width, dtype=np.int64)[None, :] < np.asarray(cnt, dtype=np.int64)[:, None]
     r_idx, k_idx = np.nonzero(valid)  # row-major: the stable sort below keeps rows ascending inside one (id, position)
     tok = ids[valid].astype(np.int64)
     if len(tok) and int(tok.max()) >= vocab:
         raise ValueError("an id is >= vocab")
+    if seg is not None:
+        tok = np.asarray(seg, dtype=np.int64)[r_idx] * vocab + tok
+        vocab = 64 * vocab
     order = np.lexsort((k_idx, tok))
     entry = (r_idx.astype(np.uint64) | (k_idx.astype(np.uint64) << np.uint64(32)) |
              (np.asarray(cnt, dtype=np.uint64)[r_idx] << np.uint64(40)))
@@ -62,6 +66,18 @@ def inverted_index(ids: np.ndarray, cnt: np.ndarray, vocab: int):
     base = post_start[:-1:5].astype(np.int64)
     post_sq = tuple(int(((post_start[c + 1:: 5].astype(np.int64) - base) ** 2).sum()) for c in range(5))
     return post, post_start, post_sq
+
+
+def levels_index_vocab(ids: np.ndarray, side: str, categories, category_mode: int, partition: bool, index: Optional[bool]) -> int:
+    """``vocab`` of a levels table's global inverted index, 0 = none: built for right tables by default, while the offsets
+    (5 per key; 64 key spaces with a category partition) stay below ``MAX_INDEX_VOCAB`` keys."""
+    if index is False or (index is None and side != "right"):
+        return 0
+    vocab = int(np.asarray(ids).max(initial=-1)) + 1
+    parts = 64 if (partition and categories is not None and category_mode != _lib.CAT_NONE) else 1
+    if vocab < 1 or (index is None and (vocab * parts > MAX_INDEX_VOCAB or np.asarray(ids).size >= (1 << 31))):
+        return 0
+    return vocab
 
 
 def pick_width(*max_counts: int) -> int:
@@ -281,13 +297,16 @@ class SetTable:
         categories: Optional[np.ndarray] = None,
         category_mode: int = _lib.CAT_NONE,
         partition: bool = True,
+        index: Optional[bool] = None,
     ) -> "SetTable":
         """Levels table.  ``items[k]`` is the level list of item k (``gen_comp_value`` output,
-        types/comparable_data.py:283-285): level l must contain level l-1 (suffix nesting)."""
+        types/comparable_data.py:283-285): level l must contain level l-1 (suffix nesting).  ``index``: build the global
+        inverted index (None = for right tables, when its offsets stay small -- ``levels_index_vocab``)."""
         ids, plen, nlev, max_levels, width = cls.encode_levels(items, vocab, width)
         cnt = (ids >= 0).sum(axis=1).astype(np.int32)
         return cls._finish(ids, cnt, side, device, width, None, nlev=nlev, plen=plen, cat=categories,
-                           max_levels=max_levels, category_mode=category_mode, partition=partition)
+                           max_levels=max_levels, category_mode=category_mode, partition=partition,
+                           index_vocab=levels_index_vocab(ids, side, categories, category_mode, partition, index))
 
     @staticmethod
     def encode_levels(items: Sequence[Sequence[Iterable[Hashable]]], vocab: Vocabulary, width: Optional[int] = None,
@@ -353,6 +372,7 @@ class SetTable:
         cls, ids: np.ndarray, plen: np.ndarray, nlev: np.ndarray, side: str, device,
         categories: Optional[np.ndarray] = None, width: Optional[int] = None,
         category_mode: int = _lib.CAT_NONE, partition: bool = True, orig: Optional[np.ndarray] = None,
+        index: Optional[bool] = None,
     ) -> "SetTable":
         """Levels table from arrays that already are in suffix-nested layout: ``ids`` [n][w] unique
         per row (negative = padding, valid ids first), ``plen`` [n][L] non-decreasing prefix lengths,
@@ -373,15 +393,14 @@ class SetTable:
         if plen.shape[1] < max_levels:  # pad with the last value (clamped level index)
             plen = np.concatenate([plen, np.repeat(plen[:, -1:], max_levels - plen.shape[1], axis=1)], axis=1)
         return cls._finish(ids, cnt, side, device, width, orig, nlev=np.asarray(nlev, dtype=np.int32), plen=plen,
-                           cat=categories, max_levels=max_levels, category_mode=category_mode, partition=partition)
+                           cat=categories, max_levels=max_levels, category_mode=category_mode, partition=partition,
+                           index_vocab=levels_index_vocab(ids, side, categories, category_mode, partition, index))
 
     @classmethod
     def _finish(cls, ids, cnt, side, device, width, orig, nlev=None, plen=None, cat=None, max_levels=0,
                 category_mode=_lib.CAT_NONE, partition=False, index_vocab=0):
         if side not in ("left", "right"):
             raise ValueError("side must be 'left' or 'right'")
-        if index_vocab and nlev is not None:
-            raise ValueError("the global inverted index is a RAW-table column")
         if nlev is not None:  # entries of plen past an item's last level repeat it (the clamped level index)
             plen = np.asarray(plen, dtype=np.uint8)
             clamp = np.minimum(np.arange(plen.shape[1])[None, :], np.maximum(np.asarray(nlev), 1)[:, None] - 1)
@@ -450,7 +469,7 @@ class SetTable:
         post = post_start = None
         post_sq = (0, 0, 0, 0, 0)
         if index_vocab:
-            post, post_start, post_sq = inverted_index(ids, cnt_s, index_vocab)
+            post, post_start, post_sq = inverted_index(ids, cnt_s, index_vocab, seg=seg)
         return cls(
             post=None if post is None else _dev(post.view(np.int64), device),
             post_start=None if post_start is None else _dev(post_start, device), vocab=int(index_vocab), post_sq=post_sq,
@@ -511,7 +530,8 @@ class SetTable:
             max_levels=max_levels, seg=new(cap, torch.int32) if do_part else None,
             seg_start=new(65, torch.int32) if do_part else None, category_mode=out_mode if levels else None,
             post=new(cap * width, torch.int64) if index_vocab else None,
-            post_start=new(5 * index_vocab + 1, torch.int32) if index_vocab else None, vocab=int(index_vocab),
+            post_start=new(5 * index_vocab * (64 if do_part else 1) + 1, torch.int32) if index_vocab else None,
+            vocab=int(index_vocab),
         )
         d_ids = _dev(np.asarray(ids, dtype=np.int32), dev)
         d_nlev = _dev(np.asarray(nlev, dtype=np.int32), dev) if levels else None

@@ -82,6 +82,11 @@ def test_set_table_levels(dev, n_cat):
             kw = dict(categories=cat, width=16, category_mode=mode, partition=part, orig=np.arange(5000, dtype=np.int32) + 11)
             _same_set_tables(tables.SetTable.from_nested_arrays(c["ids"], c["plen"], nlev, "left", dev, **kw),
                              tables.SetTable.from_nested_arrays(c["ids"], c["plen"], nlev, "left", "cpu", **kw))
+            # right tables carry the global inverted index: postings by (category segment, id) with a partition
+            g = tables.SetTable.from_nested_arrays(c["ids"], c["plen"], nlev, "right", dev, **kw)
+            assert g.post is not None and g.vocab == int(c["ids"].max()) + 1
+            assert g.post_start.shape[0] == 5 * g.vocab * (64 if g.seg is not None else 1) + 1
+            _same_set_tables(g, tables.SetTable.from_nested_arrays(c["ids"], c["plen"], nlev, "right", "cpu", **kw))
     with pytest.raises(ValueError):  # all 64 bits are real categories: no room for the "both empty" category
         bad = cat.copy()
         bad[3] |= np.uint64(1) << np.uint64(63)

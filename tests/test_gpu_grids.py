@@ -382,9 +382,14 @@ def test_jaccard_levels_random(dev, vocab, max_levels, max_new):
             assert thr > 0.9 or len(want) > 0
             got = grid.jaccard_levels_grid(lt, rt, thr, category_mode=mode, capacity=1 << 12)
             _same_hits(got, want)
-            if thr > 0.0 and width <= 32:  # candidates from the per-tile inverted index / from the signature filter
+            if thr > 0.0:
+                # candidates from the right table's global inverted index (postings by (category segment, id)) / from
+                # the per-tile LDS index / from the signature filter over all pairs
+                assert rt.post is not None and lt.post is None
                 _same_hits(grid.jaccard_levels_grid(lt, rt, thr, category_mode=mode, capacity=1 << 12, index=True), want)
                 _same_hits(grid.jaccard_levels_grid(lt, rt, thr, category_mode=mode, capacity=1 << 12, index=False), want)
+                if width <= 32:
+                    _same_hits(grid.jaccard_levels_grid(lt, rt, thr, category_mode=mode, capacity=1 << 12, index="tile"), want)
 
 
 def test_jaccard_levels_identical_items(dev):
@@ -865,8 +870,10 @@ def test_jaccard_levels_c5_shaped_low_threshold(dev, vocab):
     assert lt.seg is not None
     auto = grid.jaccard_levels_grid(lt, rt, 0.1, category_mode=mode, capacity=1 << 18)
     matrix = grid.jaccard_levels_grid(lt, rt, 0.1, category_mode=mode, capacity=1 << 18, index=False)
-    forced = grid.jaccard_levels_grid(lt, rt, 0.1, category_mode=mode, capacity=1 << 18, index=True)
-    assert auto.as_tuples() == matrix.as_tuples() == forced.as_tuples() and len(auto) > 200
+    forced = grid.jaccard_levels_grid(lt, rt, 0.1, category_mode=mode, capacity=1 << 18, index=True)      # global index
+    tile = grid.jaccard_levels_grid(lt, rt, 0.1, category_mode=mode, capacity=1 << 18, index="tile")       # per-tile index
+    assert rt.post is not None
+    assert auto.as_tuples() == matrix.as_tuples() == forced.as_tuples() == tile.as_tuples() and len(auto) > 200
     ids = lambda c: [[[int(t[1:]) for t in level] for level in item] for item in synthetic.c5_level_token_lists(c)]
     want = native.levels(False, ids(hap), ids(pop), 0.1, hap["cat"], pop["cat"], mode, cap=1 << 18)
     _same_hits(auto, want)
@@ -878,4 +885,5 @@ def test_jaccard_levels_c5_shaped_low_threshold(dev, vocab):
                                                  categories=pop["cat"][:7000], width=16, category_mode=m, partition=part)
         a = grid.jaccard_levels_grid(lt2, rt2, 0.1, category_mode=m, capacity=1 << 18, index=True)
         b = grid.jaccard_levels_grid(lt2, rt2, 0.1, category_mode=m, capacity=1 << 18, index=False)
-        assert a.as_tuples() == b.as_tuples() and len(a) > 0
+        c = grid.jaccard_levels_grid(lt2, rt2, 0.1, category_mode=m, capacity=1 << 18, index="tile")
+        assert a.as_tuples() == b.as_tuples() == c.as_tuples() and len(a) > 0
