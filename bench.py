@@ -440,6 +440,85 @@ def valu_roofline(profile_name, kernel_match, kernel_label, kernel_ms, launches_
     return roof
 
 
+def global_index_bytes(work):
+    """Algorithmic bytes of one launch of jaccard_raw_global_kernel on this workload: what the prefix-filter probe has to
+    touch whatever the implementation -- every left row (64 B of ids + its size), two offsets per probed id, every posting
+    entry of the probed lists' useful classes (8 B each), and the signature words of the candidates the entry-only tests
+    keep (not counted: data dependent, a few per cent of the entries).  Prefix lengths and posting classes as
+    csrc/jaccard_raw_global.hip computes them (the same double arithmetic for kmin)."""
+    import numpy as np
+
+    width, thr = work.left.width, work.threshold
+    kmin = {}
+    for s in range(1, 2 * width + 1):
+        kmin[s] = next((k for k in range(0, s // 2 + 1) if k / (s - k) >= thr), None)
+    prefix = np.zeros(width + 1, dtype=np.int64)
+    for a in range(1, width + 1):
+        needs = [kmin[a + b] for b in range(1, width + 1) if kmin[a + b] is not None and 1 <= kmin[a + b] <= min(a, b)]
+        if needs:
+            prefix[a] = a - min(needs) + 1
+    longest = int(prefix.max())
+    cls_end = 1 if longest <= 1 else 2 if longest <= 2 else 3 if longest <= 4 else 4 if longest <= 8 else 5
+    ids = np.asarray(work.left_np, dtype=np.int64)
+    big = np.iinfo(np.int64).max
+    ids = np.sort(np.where(ids >= 0, ids, big), axis=1)  # ascending, padding last: the table's row order
+    cnt = (ids != big).sum(axis=1)
+    probe = np.arange(ids.shape[1])[None, :] < prefix[np.minimum(cnt, width)][:, None]
+    toks = ids[probe]
+    toks = toks[toks < work.right.vocab]
+    ps = work.right.post_start.cpu().numpy().astype(np.int64)
+    visited = int((ps[5 * toks + cls_end] - ps[5 * toks]).sum())
+    return {"posting_entries_visited": visited, "probes": int(probe.sum()),
+            "bytes": visited * 8 + ids.shape[0] * (ids.shape[1] * 4 + 4) + int(probe.sum()) * 8}
+
+
+def hbm_roofline(profile_name, kernel_match, kernel_label, kernel_ms, algorithmic, n_hits, default_shape=True):
+    """Roofline of an inverted-index kernel: no operand is reused on chip (every probe walks its own posting list), so the
+    byte model of SURVEY.md 8d applies as written -- achieved = ALGORITHMIC bytes per launch / the kernel's duration (HIP
+    events), peak = 8 TB/s HBM3E, traffic = the bytes the counters saw (FETCH_SIZE x 2 + WRITE_SIZE, separate passes)."""
+    alg_bytes = algorithmic["bytes"] + n_hits * 16
+    roof = {
+        "bound": "hbm",
+        "kernel": kernel_label,
+        "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9,
+        "peak": HBM_PEAK_GBPS,
+        "unit": "GB/s",
+        "frac": alg_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+        "traffic": None,
+        "kernel_ms": kernel_ms,
+        "algorithmic_bytes_per_launch": alg_bytes,
+        "posting_entries_visited": algorithmic["posting_entries_visited"],
+        "probes": algorithmic["probes"],
+        "note": "latency- and request-bound gather kernel: the posting lists (and, for candidates, 8-byte signature words) are "
+                "fetched in 64-byte sectors, so the counters see several times the algorithmic bytes",
+    }
+    pfile = ROOT / "profiles" / f"pmc_{profile_name}.json"
+    if not default_shape:
+        roof["profile"] = "not applicable: the workload's shape was overridden on the command line"
+        return roof
+    if not pfile.exists():
+        roof["profile"] = f"{pfile.name} missing: run tools/pmc_collect.sh on the GPU box"
+        return roof
+    prof = json.loads(pfile.read_text())
+    entry = next((v for k, v in prof["kernels"].items() if kernel_match in k), None)
+    if entry is None:
+        roof["profile"] = f"{pfile.name} has no kernel matching {kernel_match!r}"
+        return roof
+    if "hbm_bytes_per_launch" in entry:
+        roof["traffic"] = entry["hbm_bytes_per_launch"]
+        roof["hbm_frac"] = roof["traffic"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
+        roof["traffic_over_algorithmic"] = roof["traffic"] / alg_bytes
+    roof["valu_issue_frac_pmc"] = entry.get("valu_issue_frac")
+    roof["salu_issue_frac"] = entry.get("salu_issue_frac")
+    roof["lds_busy_frac"] = entry.get("lds_busy_frac")
+    roof["profile"] = {
+        "file": f"profiles/{pfile.name}", "git_head": prof.get("git_head"), "csrc_sha256_16": prof.get("csrc_sha256_16"),
+        "matches_source": prof.get("csrc_sha256_16") == csrc_hash(), "kernel_us_under_pmc": entry.get("mean_us_under_pmc"),
+    }
+    roof["stale"] = not roof["profile"]["matches_source"]
+    return roof
+
+
 def cpu_baseline(work, budget_pairs):
     """The oracle's Python restatement of the reference loop on a bounded sample, one core."""
     import numpy as np
@@ -909,8 +988,11 @@ def run_raw(args, comm, device, name, rows=0, right_rows=0, threshold=None, step
                              else "launch stream"),
             "encode_and_h2d_seconds_once": round(work.encode_h2d_seconds, 4),
         },
-        "roofline": valu_roofline(work.name, work.kernel_match, work.kernel + " (exact prune on)", k_ms, 1, alg_bytes,
-                                  compulsory, default_shape=default_shape),
+        "roofline": (hbm_roofline(work.name, work.kernel_match, work.kernel + " (candidates from the right table's global "
+                                  "inverted index)", k_ms, global_index_bytes(work), n_hits, default_shape=default_shape)
+                     if work.name in ("c2", "c2low", "c4") else
+                     valu_roofline(work.name, work.kernel_match, work.kernel + " (exact prune on)", k_ms, 1, alg_bytes,
+                                   compulsory, default_shape=default_shape)),
     }
     if extras and not args.no_extras:
         # exhaustive variant (prune off): fewer repetitions, it is the slow one

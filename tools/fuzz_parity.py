@@ -113,7 +113,9 @@ def main():
         if family == "jaccard_raw":
             width = rng.choice([16, 16, 32, 64])
             # the inverted-index kernel (low thresholds) on request too, and with several chunks of left rows per block
-            index = True if (width < 64 and thr > 0 and rng.random() < 0.3) else None
+            # the right table's global inverted index (prefix filter) forced / chosen by the library, the per-tile LDS index
+            # (W <= 32), or no index at all
+            index = rng.choice([None, None, True, True, False] + (["tile"] if width < 64 else [])) if thr > 0 else None
             if index and rng.random() < 0.4:
                 n = rng.randint(1500, 7000)
             kmax = rng.randint(1, width)
@@ -186,7 +188,7 @@ def main():
                                                  partition=partition)
                 want = native.levels(False, left, right, thr, lcat, rcat, mode, cap=1 << 19)
                 # the inverted-index kernel forced / forbidden / chosen by the library (W <= 32, positive thresholds)
-                index = rng.choice([None, True, False]) if (width <= 32 and thr > 0) else None
+                index = rng.choice([None, True, True, False] + (["tile"] if width <= 32 else [])) if thr > 0 else None
                 check(grid.jaccard_levels_grid(lt, rt, thr, category_mode=mode, index=index), want,
                       f"jaccard_levels vocab={vocab} levels<={max_levels} new<={max_new} W={width} thr={thr} mode={mode} "
                       f"partition={partition} ncat={ncat} index={index} {n}x{m}")
