@@ -235,7 +235,7 @@ class Workload:
             flags = self.flag_prune if prune else _lib.FLAG_WAVE_WIDE
             _lib.check(
                 self.lib.nsm_indel_levels_grid(st[0], st[1], st[2], st[3], float(self.threshold), _lib.CAT_NONE, flags,
-                                               buf.records.data_ptr(), buf.capacity, buf.count.data_ptr(), 0, 0, stream),
+                                               buf.records.data_ptr(), buf.capacity, buf.count.data_ptr(), 0, 0, 0.0, stream),
                 self.kernel,
             )
             return
@@ -628,10 +628,29 @@ def run_c5(args, comm, device, steps=None, warmup=None, cpu=True, sub=False, wor
     state = {"threshold": float(threshold), "ws": None}
 
     def size_workspace():
-        # the split path's survivor queue is the CALLER's (ABI 4): one torch tensor, sized to the largest fuzzy grid and
-        # shared by the three (they run one after the other on the launch stream)
-        want = max(int(lib.nsm_indel_levels_workspace_bytes(g[2][0], g[2][1], g[2][2], g[2][3], state["threshold"], 1))
-                   for g in grids if g[0] == "indel")
+        # What the product's host does per grid (grid.indel_levels_grid): MEASURE on a sample of the left rows how many pairs
+        # outlive step 1 (a scan-only launch, ~1 ms at 500k x 500k), then the split path -- its queue sized to the measurement
+        # -- where few do, the shared-tile kernel where many do.  Done once here (the tables do not change between steps);
+        # the probe's time is reported beside the step (config.probe_ms_per_step).
+        # The split path's survivor queue is the CALLER's (ABI 4): one torch tensor, sized to the largest fuzzy grid and
+        # shared by the three (they run one after the other on the launch stream).
+        for timed_pass in (False, True):  # (the first pass pays one-off costs: lazy module loads, the library's side stream)
+            state["route"] = []
+            torch.cuda.synchronize(device)
+            t_probe = time.perf_counter()
+            for g in grids:
+                if g[0] != "indel":
+                    continue
+                li, ls, ri, rs = g[1]
+                extra, expected, measured = (grid.route_one_word(li, ls, ri, rs, state["threshold"], g[3])
+                                             if ls.stride == 64 and state["threshold"] > 0 else (0, 0.0, None))
+                state["route"].append({"flags": 1 | extra, "expected": expected, "measured": measured})
+                state.setdefault("route_of", {})[id(g)] = state["route"][-1]
+            torch.cuda.synchronize(device)
+            state["probe_ms"] = (time.perf_counter() - t_probe) * 1e3
+        indel = [g for g in grids if g[0] == "indel"]
+        want = max(int(lib.nsm_indel_levels_workspace_bytes(g[2][0], g[2][1], g[2][2], g[2][3], state["threshold"], r["flags"],
+                                                            r["expected"])) for g, r in zip(indel, state["route"]))
         if args.split_workspace_mb >= 0 and want > 0:
             want = args.split_workspace_mb << 20
         state["ws"] = grid.split_workspace(want, device) if want > 0 else None
@@ -646,9 +665,10 @@ def run_c5(args, comm, device, steps=None, warmup=None, cpu=True, sub=False, wor
                                              b.capacity, b.count.data_ptr(), stream)
         else:
             ws = state["ws"]
-            rc = lib.nsm_indel_levels_grid(st[0], st[1], st[2], st[3], thr, cat_mode, 1, b.records.data_ptr(),
+            r = state["route_of"][id(g)]
+            rc = lib.nsm_indel_levels_grid(st[0], st[1], st[2], st[3], thr, cat_mode, r["flags"], b.records.data_ptr(),
                                            b.capacity, b.count.data_ptr(), ws.data_ptr() if ws is not None else 0,
-                                           ws.numel() * 8 if ws is not None else 0, stream)
+                                           ws.numel() * 8 if ws is not None else 0, r["expected"], stream)
         _lib.check(rc, kind + "_levels_grid")
 
     # hit buffers sized from a counting pass (the counter keeps counting past the capacity: include/nsm_hip.h)
@@ -740,11 +760,12 @@ def run_c5(args, comm, device, steps=None, warmup=None, cpu=True, sub=False, wor
     local_pairs = len(pairs) * (hi - lo) * rows    # pairs one fuzzy pass of this rank scores
     bytes_per_pair = 2 * 4 * 64                     # both items' level storage: 4 level strings of 64 B each
     str_bytes = sum(t.nbytes() for g in grids if g[0] == "indel" for t in (g[1][1], g[1][3]))
+    tiled = (not split_used) and (threshold < 0.55 or any(r["flags"] & _lib.FLAG_TILE for r in state["route"]))
     if split_used:
         kernel_match = ("indel_levels_park_kernel<1, true>", "indel_levels_finish_kernel", "split_begin_kernel")
         kernel_label = ("nsm_indel_levels_grid, split path: indel_levels_park_kernel<1, true> (scan) + "
                         "indel_levels_finish_kernel per round (3 grid calls per step)")
-    elif threshold < 0.55:  # (csrc/indel_levels.hip: NSM_TILE_K1_BELOW -- most pairs outlive step 1 there)
+    elif tiled:  # (many pairs outlive step 1: measured by the probe; csrc/indel_levels.hip takes it by itself below 0.55)
         kernel_match = "indel_levels_tile_kernel<1>"
         kernel_label = "nsm_indel_levels_grid, shared-tile kernel: indel_levels_tile_kernel<1> (3 grid calls per step)"
     else:
@@ -786,7 +807,9 @@ def run_c5(args, comm, device, steps=None, warmup=None, cpu=True, sub=False, wor
             "fuzzy_grids_ms_per_step": ms_indel,
             "jaccard_grids_ms_per_step": ms_jac,
             "fuzzy_path": ("split (scan -> survivor queue in a caller-owned workspace -> finish)" if split_used else
-                           "shared-tile kernel" if threshold < 0.55 else "single kernel (scan + park + dense finish)"),
+                           "shared-tile kernel" if tiled else "single kernel (scan + park + dense finish)"),
+            "fuzzy_route_measured": [r["measured"] for r in state["route"]],
+            "probe_ms_per_step": state.get("probe_ms"),
             "split_workspace_bytes": int(state["ws"].numel() * 8) if split_used else 0,
             "split_queue_overflowed": bool(m["overflow_word"]) if split_used else None,
         },

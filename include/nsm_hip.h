@@ -182,6 +182,17 @@ typedef struct nsm_level_items {
                              park, dense finish inside the kernel) -- instead of the shared-tile kernel for strings beyond 64
                              code units, and instead of the split path (scan kernel -> survivor queue -> finish kernel) that
                              strings up to 64 code units take at thresholds >= 0.7; same hits, A/B runs and tests */
+#define NSM_FLAG_SPLIT 128u /* nsm_indel_levels_grid, strings up to 64 code units: take the split path (given a workspace) at ANY
+                              threshold -- by itself the library only does from 0.7 up, where few pairs outlive step 1 on
+                              every corpus it was measured on; a host that has MEASURED the survival rate (NSM_FLAG_PROBE)
+                              knows better */
+#define NSM_FLAG_TILE 256u  /* the same grids: the shared-tile kernel (level strings resident in LDS, survivors carried on
+                              wave-wide) -- what pays when MANY pairs outlive step 1; by itself the library takes it below
+                              0.55 */
+#define NSM_FLAG_PROBE 512u /* the same grids, with NSM_FLAG_SPLIT and a workspace: run the scan kernel ONLY -- no finish kernel,
+                              no fallback, no hit is written; the workspace's queue counters (words 2 ..) then hold the number
+                              of pairs that outlive step 1 (they keep counting past the queue's capacity).  A host probes a
+                              SAMPLE of the left rows this way and sizes / routes the real call from the count */
 #define NSM_FLAG_WAVE_WIDE 2u /* nsm_indel_levels_grid: score every step wave-wide (no block-cooperative
                                  parking of the surviving pairs); same hits, kept for A/B runs and tests */
 
@@ -221,15 +232,20 @@ int nsm_indel_raw_grid(const nsm_str_table* left, const nsm_str_table* right, do
  * Besides the workspace the split path uses a side stream and four events per caller stream (the finish kernel of round
  * k runs beside the scan of round k + 1); they hold no device memory, are created at the first such call on a stream
  * and destroyed by nsm_release().  A call on a stream that is being captured uses `stream` alone.
- * Hits are appended behind the records already counted in hit_count, as everywhere. */
+ * Hits are appended behind the records already counted in hit_count, as everywhere.
+ *
+ * `expected_survivors`: the caller's estimate of the number of pairs that outlive step 1 (<= 0: the library's guess, 2 % of
+ * the pairs a grid visits) -- it decides the queue size nsm_indel_levels_workspace_bytes() asks for and the number of
+ * rounds the grid makes with the workspace it is given.  A wrong estimate costs time (more rounds, or the overflow
+ * path), never a hit. */
 uint64_t nsm_indel_levels_workspace_bytes(const nsm_level_items* left, const nsm_str_table* left_strings,
                                           const nsm_level_items* right, const nsm_str_table* right_strings,
-                                          double threshold, uint32_t flags);
+                                          double threshold, uint32_t flags, double expected_survivors);
 int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_table* left_strings,
                           const nsm_level_items* right, const nsm_str_table* right_strings,
                           double threshold, int32_t category_mode, uint32_t flags, nsm_hit* hits,
                           uint64_t capacity, unsigned long long* hit_count, void* workspace,
-                          uint64_t workspace_bytes, void* stream);
+                          uint64_t workspace_bytes, double expected_survivors, void* stream);
 
 /* Destroy the side stream and events the library created for `stream` on the current device.  The caller makes sure no nsm_indel_levels_grid work is still queued on that stream.  Returns 0. */
 int nsm_release(void* stream);

@@ -376,7 +376,8 @@ static bool split_eligible(const nsm_level_items* left, const nsm_str_table* lef
   if (left_strings->alphabet != right_strings->alphabet || left_strings->alphabet < 1) return false;
   if (flags & (NSM_FLAG_PARK | NSM_FLAG_WAVE_WIDE)) return false;
   if (!(flags & NSM_FLAG_PRUNE) || !left_strings->hist || !right_strings->hist) return false;
-  if (!(threshold >= NSM_SPLIT_MIN_THRESHOLD)) return false;
+  if (!(threshold >= NSM_SPLIT_MIN_THRESHOLD) && !(flags & NSM_FLAG_SPLIT)) return false;
+  if (flags & NSM_FLAG_TILE) return false;
   if ((left_strings->alphabet + 1 + 7) / 8 * 8 > 64) return false;  // the scan's two 64-entry tables
   if (left->n <= 0 || right->n <= 0 || left->n >= (1 << kQueueRowBits) || right->n >= (1 << kQueueRowBits)) return false;
   *expect = static_cast<double>(left->n) * static_cast<double>(right->n) * 0.02 * (left->seg ? 1.0 / 16 : 1.0);
@@ -387,10 +388,11 @@ static bool split_eligible(const nsm_level_items* left, const nsm_str_table* lef
 
 extern "C" uint64_t nsm_indel_levels_workspace_bytes(const nsm_level_items* left, const nsm_str_table* left_strings,
                                                      const nsm_level_items* right, const nsm_str_table* right_strings,
-                                                     double threshold, uint32_t flags) {
+                                                     double threshold, uint32_t flags, double expected_survivors) {
   using namespace nsm;
   double expect = 0.0;
   if (!split_eligible(left, left_strings, right, right_strings, threshold, flags, &expect)) return 0;
+  if (expected_survivors > 0.0) expect = expected_survivors;
   const unsigned long long qmax = NSM_SPLIT_QUEUE_MAX;
   const unsigned long long rounds = static_cast<unsigned long long>(expect / static_cast<double>(qmax)) + 1;
   unsigned long long entries = static_cast<unsigned long long>(expect / static_cast<double>(rounds)) + (1ull << 16);
@@ -445,7 +447,7 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
                                      const nsm_level_items* right, const nsm_str_table* right_strings,
                                      double threshold, int32_t category_mode, uint32_t flags, nsm_hit* hits,
                                      uint64_t capacity, unsigned long long* hit_count, void* workspace,
-                                     uint64_t workspace_bytes, void* stream) {
+                                     uint64_t workspace_bytes, double expected_survivors, void* stream) {
   using namespace nsm;
   if (!left || !right || !left_strings || !right_strings || !hit_count || (!hits && capacity)) {
     set_error("nsm_indel_levels_grid: null argument");
@@ -535,7 +537,12 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
 #ifndef NSM_TILE_K1_BELOW
 #define NSM_TILE_K1_BELOW 0.55
 #endif
-  const bool tile_ok = K > 1 || threshold < NSM_TILE_K1_BELOW;
+  // (NSM_FLAG_TILE / NSM_FLAG_SPLIT: a host that has measured the survival rate of step 1 -- NSM_FLAG_PROBE on a sample of
+  // the left rows -- routes by it: measured on configs[4]-shaped cohorts, 3 x 100k^2, ms: word-like text at 0.55 / 0.6
+  // (2.8 % / 0.09 % survive) split 13.9 / 10.5, fused 20.0 / 16.4, tile 30.9 / 25.3; digit strings at 0.6 / 0.65 / 0.675
+  // (most / 60 % / 21 % survive) tile 72.7 / 43.5 / 38.4, fused 123.9 / 81.2 / 33.0, split - / 112.9 / 43.1)
+  const bool want_split = (flags & NSM_FLAG_SPLIT) && workspace != nullptr && !(flags & NSM_FLAG_TILE);
+  const bool tile_ok = K > 1 || (flags & NSM_FLAG_TILE) || (threshold < NSM_TILE_K1_BELOW && !want_split);
   if (!(flags & NSM_FLAG_WAVE_WIDE) && tile_ok && !(flags & NSM_FLAG_PARK)) {
     // multi-word strings: shared-tile kernel (indel_levels_tile.hpp) -- the waves of a block share one right tile
     // whose level strings stay resident in LDS, and divide the left rows
@@ -666,6 +673,13 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
     double expect = 0.0;
     const bool split = workspace != nullptr && workspace_bytes >= kSplitMinWorkspace &&
                        split_eligible(left, left_strings, right, right_strings, threshold, flags, &expect);
+    if (expected_survivors > 0.0) expect = expected_survivors;
+    const bool probe = (flags & NSM_FLAG_PROBE) != 0;
+    if (probe && !split) {
+      set_error("nsm_indel_levels_grid: NSM_FLAG_PROBE needs NSM_FLAG_SPLIT, a workspace and a grid the split path takes "
+                "(strings up to 64 code units with histograms, NSM_FLAG_PRUNE)");
+      return NSM_E_BADARG;
+    }
     const size_t fixed_wave = (K > 1 ? 16 * K * kWave * 4 + batch * kWave * 8 : 0) + batch * kWave * 2 +
                               batch * 3 * kHeadDwords * 4 + batch * kWave * K;
     const int sub = park_sub(K);
@@ -774,11 +788,13 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
           if (e == hipSuccess) e = hipStreamWaitEvent(fs, ws.scanned[half], 0);
           if (e != hipSuccess) return hip_status(e, "split path: scan -> finish ordering");
         }
-        hipLaunchKernelGGL(indel_levels_finish_kernel, dim3(kFinishBlocks), dim3(kWave),
-                           static_cast<size_t>(fp.pm_stride) * 2 * kWave * 4, fs, left->first, left->nlev, left->orig,
-                           left_strings->codes, left_strings->len, left_strings->hist, right->first, right->nlev,
-                           right->orig, right_strings->codes, right_strings->len, right_strings->hist, hits, hit_count,
-                           qhalf, ctl + 2 + rd, qflag, fp);
+        if (!probe) {  // (NSM_FLAG_PROBE: the scan's queue counters are all the caller wants)
+          hipLaunchKernelGGL(indel_levels_finish_kernel, dim3(kFinishBlocks), dim3(kWave),
+                             static_cast<size_t>(fp.pm_stride) * 2 * kWave * 4, fs, left->first, left->nlev, left->orig,
+                             left_strings->codes, left_strings->len, left_strings->hist, right->first, right->nlev,
+                             right->orig, right_strings->codes, right_strings->len, right_strings->hist, hits, hit_count,
+                             qhalf, ctl + 2 + rd, qflag, fp);
+        }
         if (ws.side) {
           const hipError_t e = hipEventRecord(ws.finished[half], fs);
           if (e != hipSuccess) return hip_status(e, "hipEventRecord(finished)");
@@ -790,6 +806,7 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
           if (e != hipSuccess) return hip_status(e, "hipStreamWaitEvent(join)");
         }
       }
+      if (probe) return hip_status(hipGetLastError(), "nsm_indel_levels_grid (probe)");  // the counters are the result
       hipLaunchKernelGGL(split_end_kernel, dim3(1), dim3(kWave), 0, hs, ctl, hit_count);
       gate = qflag;
       }

@@ -12,6 +12,7 @@ FLAG_WAVE_WIDE = 2  # nsm_indel_levels_grid without the block-cooperative parkin
 FLAG_INDEX, FLAG_NO_INDEX = 4, 8  # nsm_jaccard_raw_grid: force / forbid the inverted-index kernels
 FLAG_TILE_INDEX = 64  # with FLAG_INDEX: the per-tile LDS index even when the right table carries a global one
 FLAG_RAW_SCORE = 32  # nsm_*_any_grid: the RAW plugin call instead of compare_terms
+FLAG_SPLIT, FLAG_TILE, FLAG_PROBE = 128, 256, 512  # nsm_indel_levels_grid, one-word strings: force the split path / the tile kernel; scan only
 FLAG_PARK = 16  # nsm_indel_levels_grid, strings > 64 code units: the round-2 park kernel instead of the shared-tile kernel
 BUILD_PARTITION, BUILD_VALIDATE, BUILD_SORT = 1, 2, 4
 CAT_NONE, CAT_INTERSECT, CAT_INTERSECT_OR_BOTH_EMPTY = 0, 1, 2
@@ -135,13 +136,13 @@ def load() -> ctypes.CDLL:
     lib.nsm_jaccard_levels_grid.argtypes = [
         P(NsmSetTable), P(NsmSetTable), ctypes.c_double, ctypes.c_int32, ctypes.c_uint32] + grid_tail
     lib.nsm_indel_raw_grid.argtypes = [P(NsmStrTable), P(NsmStrTable), ctypes.c_double, ctypes.c_uint32] + grid_tail
-    # hits, capacity, hit_count, workspace, workspace_bytes, stream
+    # hits, capacity, hit_count, workspace, workspace_bytes, expected_survivors, stream
     lib.nsm_indel_levels_grid.argtypes = [
         P(NsmLevelItems), P(NsmStrTable), P(NsmLevelItems), P(NsmStrTable),
         ctypes.c_double, ctypes.c_int32, ctypes.c_uint32, ctypes.c_void_p, c_u64, ctypes.c_void_p, ctypes.c_void_p, c_u64,
-        ctypes.c_void_p]
+        ctypes.c_double, ctypes.c_void_p]
     lib.nsm_indel_levels_workspace_bytes.argtypes = [
-        P(NsmLevelItems), P(NsmStrTable), P(NsmLevelItems), P(NsmStrTable), ctypes.c_double, ctypes.c_uint32]
+        P(NsmLevelItems), P(NsmStrTable), P(NsmLevelItems), P(NsmStrTable), ctypes.c_double, ctypes.c_uint32, ctypes.c_double]
     lib.nsm_release.argtypes = [ctypes.c_void_p]
     lib.nsm_release_all.argtypes = []
     lib.nsm_indel_any_grid.argtypes = [

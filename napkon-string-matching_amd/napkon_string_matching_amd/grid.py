@@ -204,15 +204,86 @@ def jaccard_levels_grid(
     return run_grid(launch, left.ids.device, capacity, "nsm_jaccard_levels_grid", defer=defer)
 
 
+PROBE_MIN_PAIRS = 1 << 27      # grids of at least this many pairs are probed before they are routed (11 600 x 11 600)
+PROBE_LEFT_ROWS = 8192          # left rows of the probe's sample
+SPLIT_MAX_SURVIVAL = 0.10       # of the pairs a grid visits: up to here the split path, beyond it the shared-tile kernel
+
+
+def _visited_pairs(left: LevelItems, right: LevelItems) -> float:
+    """Pairs the one-word kernels score step 1 for: all of them, or -- partitioned tables -- the same-category ones."""
+    if left.seg_start is None or right.seg_start is None:
+        return float(left.n) * float(right.n)
+    a = left.seg_start.cpu().numpy().astype(np.float64)
+    b = right.seg_start.cpu().numpy().astype(np.float64)
+    return float(((a[1:] - a[:-1]) * (b[1:] - b[:-1])).sum())
+
+
+def probe_survival(left: LevelItems, left_strings: StrTable, right: LevelItems, right_strings: StrTable, threshold: float,
+                   category_mode: int):
+    """MEASURE, on a sample of the left rows, how many pairs outlive step 1 of ``compare_terms`` x ``fuzzy_match`` on this
+    grid (one-word level strings): every k-th row of the left items table (the rows stay grouped by category and ordered by
+    depth) against the whole right side through the scan kernel alone (``NSM_FLAG_PROBE``), the survivors read from the
+    workspace's queue counters.  Returns (expected survivors of the full grid, pairs the full grid visits), or None when
+    the grid is not one the split path could take.  Which path is fastest depends on that rate and nothing else that a
+    threshold could tell: word-like text at 0.55 lets 2.8 % of the same-category pairs through, digit strings at 0.65
+    about 60 %."""
+    lib = _lib.load()
+    dev = left.first.device
+    k = max(1, left.n // PROBE_LEFT_ROWS)
+    idx = torch.arange(0, left.n, k, device=dev)
+    seg = seg_start = None
+    if left.seg is not None:
+        seg = left.seg[idx].contiguous()
+        seg_start = torch.zeros(65, dtype=torch.int32, device=dev)
+        seg_start[1:] = torch.cumsum(torch.bincount(seg, minlength=64)[:64], 0).to(torch.int32)
+    sample = LevelItems(first=left.first[idx].contiguous(), nlev=left.nlev[idx].contiguous(), orig=left.orig[idx].contiguous(),
+                        cat=None if left.cat is None else left.cat[idx].contiguous(), n=int(idx.numel()), seg=seg,
+                        seg_start=seg_start, category_mode=left.category_mode)
+    flags = _lib.FLAG_PRUNE | _lib.FLAG_SPLIT | _lib.FLAG_PROBE
+    si, ls, ri, rs = sample.struct(), left_strings.struct(), right.struct(), right_strings.struct()
+    if int(lib.nsm_indel_levels_workspace_bytes(si, ls, ri, rs, float(threshold), flags, 0.0)) == 0:
+        return None
+    ws = torch.zeros(64 + 2 * (1 << 16), dtype=torch.int64, device=dev)  # control words + two small queue halves
+    count = torch.zeros(1, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    _lib.check(lib.nsm_indel_levels_grid(si, ls, ri, rs, float(threshold), int(category_mode), flags, 0, 0, count.data_ptr(),
+                                         ws.data_ptr(), ws.numel() * 8, 1.0, stream), "nsm_indel_levels_grid (probe)")
+    # (expected survivors 1: ONE round over the sample whatever the queue holds -- only the counters matter)
+    survivors = float(ws[2:64].sum().item())  # (synchronises; the counters keep counting past the queue's capacity)
+    visited_sample = _visited_pairs(sample, right)
+    visited = _visited_pairs(left, right)
+    if visited_sample <= 0:
+        return 0.0, visited
+    return survivors / visited_sample * visited, visited
+
+
+def route_one_word(left: LevelItems, left_strings: StrTable, right: LevelItems, right_strings: StrTable, threshold: float,
+                   category_mode: int):
+    """(extra flags, expected survivors, what was measured) for a large grid of one-word level strings: probe, then the split
+    path when few pairs outlive step 1, the shared-tile kernel when many do.  (0, 0.0, None): leave it to the library."""
+    got = probe_survival(left, left_strings, right, right_strings, threshold, category_mode)
+    if got is None:
+        return 0, 0.0, None
+    expected, visited = got
+    rate = expected / visited if visited > 0 else 0.0
+    if rate <= SPLIT_MAX_SURVIVAL:
+        # (sampling error: a quarter more queue than the estimate)
+        return _lib.FLAG_SPLIT, max(1.0, 1.25 * expected), {"survival_rate": rate, "path": "split", "pairs_visited": visited}
+    return _lib.FLAG_TILE, 0.0, {"survival_rate": rate, "path": "tile", "pairs_visited": visited}
+
+
 def indel_levels_grid(
     left: LevelItems, left_strings: StrTable, right: LevelItems, right_strings: StrTable, threshold: float,
     category_mode: int = _lib.CAT_NONE, prune: bool = True, capacity: Optional[int] = None, wave_wide: bool = False,
     park: bool = False, workspace: Optional[int] = None, return_overflow: Optional[list] = None, defer: bool = False,
+    probe: Optional[bool] = None, route: Optional[list] = None,
 ) -> Hits:
     """``compare_terms`` with ``fuzzy_match`` over per-level strings.  ``wave_wide`` selects the kernel
     without block-cooperative parking, ``park`` the round-2 kernel for multi-word strings (same hits; A/B runs
     and tests).  ``workspace``: bytes of split-path scratch to hand to the library (None = what it asks for, 0 = none:
-    the single-kernel path); ``return_overflow``: a list that receives the workspace's overflow word (tests)."""
+    the single-kernel path); ``return_overflow``: a list that receives the workspace's overflow word (tests).
+    ``probe``: measure the survival rate of step 1 on a sample first and route by it (None = for large grids of one-word
+    strings; ``route`` receives what was decided)."""
     lib = _lib.load()
     li, ls, ri, rs = left.struct(), left_strings.struct(), right.struct(), right_strings.struct()
     flags = (_lib.FLAG_PRUNE if prune else 0) | (_lib.FLAG_WAVE_WIDE if wave_wide else 0) | (_lib.FLAG_PARK if park else 0)
@@ -221,16 +292,28 @@ def indel_levels_grid(
     if left.category_mode is not None:  # the encoder may have rewritten the predicate (partition)
         category_mode = left.category_mode
 
-    # the split path's survivor queue (scan kernel -> queue -> finish kernel; one-word strings at thresholds >= 0.7) is
-    # CALLER-owned scratch: a torch tensor, so torch's allocator owns it and it goes back to the cache with this call
     dev = left.first.device
-    want = int(lib.nsm_indel_levels_workspace_bytes(li, ls, ri, rs, float(threshold), flags)) if workspace is None else int(workspace)
+    expected = 0.0
+    if probe is None:
+        probe = (workspace is None and prune and not wave_wide and not park and left_strings.stride == 64 and threshold > 0 and
+                 float(left.n) * float(right.n) >= PROBE_MIN_PAIRS)
+    if probe:
+        extra, expected, measured = route_one_word(left, left_strings, right, right_strings, threshold, category_mode)
+        flags |= extra
+        if route is not None and measured is not None:
+            route.append(dict(measured, expected_survivors=expected))
+    # the split path's survivor queue (scan kernel -> queue -> finish kernel; one-word strings at thresholds >= 0.7, or
+    # wherever the probe found few survivors) is CALLER-owned scratch: a torch tensor, so torch's allocator owns it and it
+    # goes back to the cache with this call
+    want = int(lib.nsm_indel_levels_workspace_bytes(li, ls, ri, rs, float(threshold), flags, float(expected))) if workspace is None \
+        else int(workspace)
     ws = split_workspace(want, dev) if want > 0 else None
 
     def launch(buf: HitBuffer, stream: int) -> int:
         return lib.nsm_indel_levels_grid(
             li, ls, ri, rs, float(threshold), int(category_mode), flags, buf.records.data_ptr(), buf.capacity,
-            buf.count.data_ptr(), ws.data_ptr() if ws is not None else 0, ws.numel() * 8 if ws is not None else 0, stream,
+            buf.count.data_ptr(), ws.data_ptr() if ws is not None else 0, ws.numel() * 8 if ws is not None else 0, float(expected),
+            stream,
         )
 
     hits = run_grid(launch, dev, capacity, "nsm_indel_levels_grid", defer=defer)  # (returns after the stream has been synchronised)

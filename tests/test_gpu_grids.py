@@ -513,11 +513,11 @@ def test_indel_levels_split_path(dev, thr, extra):
         assert len(want) > 50
         fused = grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, capacity=1 << 16, park=True)
         _same_hits(fused, want)
-        asked = int(lib.nsm_indel_levels_workspace_bytes(li.struct(), ls.struct(), ri.struct(), rs.struct(), thr, _lib.FLAG_PRUNE))
+        asked = int(lib.nsm_indel_levels_workspace_bytes(li.struct(), ls.struct(), ri.struct(), rs.struct(), thr, _lib.FLAG_PRUNE, 0.0))
         assert asked > 512 + 16 * 65536  # the grid qualifies for the split path
-        assert lib.nsm_indel_levels_workspace_bytes(li.struct(), ls.struct(), ri.struct(), rs.struct(), 0.5, _lib.FLAG_PRUNE) == 0
+        assert lib.nsm_indel_levels_workspace_bytes(li.struct(), ls.struct(), ri.struct(), rs.struct(), 0.5, _lib.FLAG_PRUNE, 0.0) == 0
         assert lib.nsm_indel_levels_workspace_bytes(li.struct(), ls.struct(), ri.struct(), rs.struct(), thr,
-                                                    _lib.FLAG_PRUNE | _lib.FLAG_PARK) == 0
+                                                    _lib.FLAG_PRUNE | _lib.FLAG_PARK, 0.0) == 0
         # None = what the library asks for; 0 = no workspace (single-kernel path); the small ones overflow (queue halves of
         # 32, 100 and 5000 entries), 1024 bytes is the smallest workspace the library uses at all
         for nbytes in (None, 0, 1024, 512 + 16 * 100, 512 + 16 * 5000):
@@ -539,7 +539,7 @@ def test_indel_levels_split_path(dev, thr, extra):
             ws = torch.empty(max(1, (nbytes if nbytes is not None else asked) // 8), dtype=torch.int64, device=dev)
             _lib.check(lib.nsm_indel_levels_grid(li.struct(), ls.struct(), ri.struct(), rs.struct(), thr, int(cm), _lib.FLAG_PRUNE,
                                                  buf.records.data_ptr(), buf.capacity, buf.count.data_ptr(), ws.data_ptr(),
-                                                 nbytes if nbytes is not None else asked,
+                                                 nbytes if nbytes is not None else asked, 0.0,
                                                  torch.cuda.current_stream(dev).cuda_stream), "nsm_indel_levels_grid")
             assert int(buf.count.item()) == 5 + len(want)
     assert lib.nsm_release(torch.cuda.current_stream(dev).cuda_stream) == 0  # the side stream and events of this stream
@@ -586,7 +586,7 @@ def test_indel_levels_split_path_many_rounds(dev, partition):
         buf = grid.HitBuffer(1 << 20, dev)
         buf.reset()
         _lib.check(lib.nsm_indel_levels_grid(li.struct(), ls.struct(), ri.struct(), rs.struct(), 0.7, int(cm), _lib.FLAG_PRUNE,
-                                             buf.records.data_ptr(), buf.capacity, buf.count.data_ptr(), ws.data_ptr(), nbytes,
+                                             buf.records.data_ptr(), buf.capacity, buf.count.data_ptr(), ws.data_ptr(), nbytes, 0.0,
                                              torch.cuda.current_stream(dev).cuda_stream), "nsm_indel_levels_grid")
         n = int(buf.count.item())
         ctl = ws[:64].cpu().numpy()
@@ -597,6 +597,60 @@ def test_indel_levels_split_path_many_rounds(dev, partition):
         got = grid.sort_hits_device(buf, n)
         assert got.as_tuples() == fused.as_tuples(), (partition, rounds_wanted)
     assert max(seen_rounds) >= 8
+
+
+def test_indel_levels_probe_and_route(dev):
+    """The host MEASURES how many pairs outlive step 1 on a sample of the left rows (NSM_FLAG_PROBE: scan kernel only, the
+    queue counters are the result, no hit is written) and routes by it: few survivors -> the split path at ANY threshold
+    (NSM_FLAG_SPLIT, queue sized to the measurement), many -> the shared-tile kernel (NSM_FLAG_TILE).  Whatever the route,
+    the hits are the fused kernel's (which the oracle pins elsewhere): word-like text at 0.55 (split), digit strings at
+    0.6 (tile), both forced routes on one grid."""
+    from napkon_string_matching_amd import _lib, grid, synthetic, tables
+
+    lib = _lib.load()
+    mode = _lib.CAT_INTERSECT_OR_BOTH_EMPTY
+    lex = synthetic.word_vocabulary(5000)
+    cases = {}
+    for name, kw in (("words", dict(lex=lex)), ("digits", dict())):
+        hap = synthetic.c5_cohort(9000, 31, **kw)
+        pop = synthetic.c5_cohort(16000, 32, plant_from=hap, plant_fraction=0.02, **kw)
+        cases[name] = tables.encode_level_codes(synthetic.c5_level_codes(hap), synthetic.c5_level_codes(pop),
+                                                len(synthetic.c5_alphabet(hap)), dev, hap["cat"], pop["cat"], mode)
+    for name, thr, want_path in (("words", 0.55, "split"), ("words", 0.7, "split"), ("digits", 0.6, "tile"), ("digits", 0.7, "split")):
+        li, ls, ri, rs = cases[name]
+        fused = grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, park=True, capacity=1 << 22)
+        assert len(fused) > 50
+        # the probe leaves the caller's hit counter alone and reports a sensible rate
+        expected, visited = grid.probe_survival(li, ls, ri, rs, thr, li.category_mode)
+        assert visited > 1e6 and 0.0 <= expected <= visited
+        route = []
+        got = grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, capacity=1 << 22, probe=True, route=route)
+        assert route and route[0]["path"] == want_path, (name, thr, route)
+        assert got.as_tuples() == fused.as_tuples(), (name, thr, route)
+        # the measured expectation sizes the queue: no overflow on the split route
+        if want_path == "split":
+            flag = []
+            again = grid.indel_levels_grid(li, ls, ri, rs, thr, category_mode=mode, capacity=1 << 22, probe=True, return_overflow=flag)
+            assert flag == [0] and again.as_tuples() == fused.as_tuples()
+    # both routes forced on ONE grid, at a threshold where the library by itself would take neither
+    li, ls, ri, rs = cases["words"]
+    fused = grid.indel_levels_grid(li, ls, ri, rs, 0.6, category_mode=mode, park=True, capacity=1 << 22).as_tuples()
+    for extra in (_lib.FLAG_SPLIT, _lib.FLAG_TILE):
+        buf = grid.HitBuffer(1 << 22, dev)
+        buf.reset()
+        ws = torch.empty((512 + 16 * (1 << 20)) // 8, dtype=torch.int64, device=dev)
+        _lib.check(lib.nsm_indel_levels_grid(li.struct(), ls.struct(), ri.struct(), rs.struct(), 0.6, int(li.category_mode),
+                                             _lib.FLAG_PRUNE | extra, buf.records.data_ptr(), buf.capacity, buf.count.data_ptr(),
+                                             ws.data_ptr(), ws.numel() * 8, 0.0, torch.cuda.current_stream(dev).cuda_stream),
+                   "nsm_indel_levels_grid")
+        n = int(buf.count.item())
+        assert grid.sort_hits_device(buf, n).as_tuples() == fused, extra
+    # NSM_FLAG_PROBE without NSM_FLAG_SPLIT / a workspace is an argument error, not a silent full run
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    rc = lib.nsm_indel_levels_grid(li.struct(), ls.struct(), ri.struct(), rs.struct(), 0.6, int(li.category_mode),
+                                   _lib.FLAG_PRUNE | _lib.FLAG_PROBE, 0, 0, cnt.data_ptr(), 0, 0, 0.0,
+                                   torch.cuda.current_stream(dev).cuda_stream)
+    assert rc == 10001
 
 
 def test_indel_levels_split_path_under_graph_capture(dev):
@@ -621,7 +675,7 @@ def test_indel_levels_split_path_under_graph_capture(dev):
     want = grid.indel_levels_grid(li, ls, ri, rs, 0.7, park=True).as_tuples()
     assert len(want) > 100
     lib = _lib.load()
-    asked = int(lib.nsm_indel_levels_workspace_bytes(li.struct(), ls.struct(), ri.struct(), rs.struct(), 0.7, _lib.FLAG_PRUNE))
+    asked = int(lib.nsm_indel_levels_workspace_bytes(li.struct(), ls.struct(), ri.struct(), rs.struct(), 0.7, _lib.FLAG_PRUNE, 0.0))
     assert asked > 0
 
     def hits_of(buf):
@@ -636,7 +690,7 @@ def test_indel_levels_split_path_under_graph_capture(dev):
             buf.count.zero_()
             _lib.check(lib.nsm_indel_levels_grid(li.struct(), ls.struct(), ri.struct(), rs.struct(), 0.7, _lib.CAT_NONE,
                                                  _lib.FLAG_PRUNE, buf.records.data_ptr(), buf.capacity, buf.count.data_ptr(),
-                                                 ws.data_ptr() if ws is not None else 0, asked if ws is not None else 0,
+                                                 ws.data_ptr() if ws is not None else 0, asked if ws is not None else 0, 0.0,
                                                  stream.cuda_stream), "nsm_indel_levels_grid")
 
         stream = torch.cuda.Stream(dev)

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--vocab", type=int, default=20_000)
     ap.add_argument("--jaccard-flags", type=int, default=1, help="flags of nsm_jaccard_levels_grid: 1 | 4 (force index) | 8 (no index)")
     ap.add_argument("--indel-flags", type=int, default=1, help="flags of nsm_indel_levels_grid: 1 | 16 (the fused park kernel)")
+    ap.add_argument("--workspace-mb", type=int, default=-1, help="split-path workspace handed to nsm_indel_levels_grid (-1 = what the library asks for)")
     ap.add_argument("--words", action="store_true", help="word-like tokens (synthetic.word_vocabulary) instead of t<digits>: the c5w corpus")
     ap.add_argument("--tile-stats", action="store_true", help="variant build with -DNSM_TILE_STATS: print the shared-tile kernel's work counters")
     ap.add_argument("--scan-stats", action="store_true", help="variant build with -DNSM_SCAN_STATS: print the scan's work counters")
@@ -83,7 +84,9 @@ def main():
         lib.nsm_sort_hits(buf.records.data_ptr(), buf.scratch.data_ptr(), buf.capacity, buf.count.data_ptr(), 0, args.rows, stream)
 
     ws_bytes = max(int(lib.nsm_indel_levels_workspace_bytes(t[0].struct(), t[1].struct(), t[2].struct(), t[3].struct(),
-                                                            args.threshold, args.indel_flags)) for t in str_tables.values())
+                                                            args.threshold, args.indel_flags, 0.0)) for t in str_tables.values())
+    if args.workspace_mb >= 0 and ws_bytes:
+        ws_bytes = args.workspace_mb << 20
     ws = grid.split_workspace(ws_bytes, dev) if ws_bytes else None  # the split path's survivor queue: caller-owned (ABI 4)
 
     def run_indel(a, b):
@@ -92,7 +95,7 @@ def main():
         _lib.check(lib.nsm_indel_levels_grid(li.struct(), ls.struct(), ri.struct(), rs.struct(), args.threshold,
                                              li.category_mode, args.indel_flags, buf.records.data_ptr(), buf.capacity, buf.count.data_ptr(),
                                              ws.data_ptr() if ws is not None else 0, ws.numel() * 8 if ws is not None else 0,
-                                             stream), "indel_levels")
+                                             0.0, stream), "indel_levels")
         lib.nsm_sort_hits(buf.records.data_ptr(), buf.scratch.data_ptr(), buf.capacity, buf.count.data_ptr(), 0, args.rows, stream)
 
     out = {"rows_per_cohort": args.rows, "threshold": args.threshold, "pairs_per_grid": args.rows ** 2,
@@ -112,6 +115,10 @@ def main():
             fn(a, b)
             hits.append(int(buf.count.item()))
         out[label] = {"ms_per_3_grids": dt * 1e3, "pairs_per_s": 3 * args.rows ** 2 / dt, "hits": hits}
+        if label == "fuzzy_match" and ws is not None:
+            ctl = ws[:64].cpu().numpy()
+            out[label]["split_overflowed"] = bool(int(ctl[1]) & 0xFFFFFFFF)
+            out[label]["split_round_survivors_last_grid"] = [int(v) for v in ctl[2:64] if v > 0]
 
     if args.scan_stats:
         import ctypes
