@@ -355,8 +355,10 @@ int nsm_jaccard_any_grid(const nsm_any_sets* left, const nsm_any_sets* right, do
  *   n_hint    0, or the caller's promise that at most n_hint records are live (a host that has read the counter knows):
  *             the launch geometry then follows n_hint instead of capacity -- one launch up to 8192 records whatever the
  *             buffer's size.  With more live records than promised the order is unspecified (no record is lost).
- *   id_limit  0, or the caller's promise that every i and j is in [0, id_limit) (the larger cohort's size): fewer key
- *             bits to sort above 8192 records. */
+ *   id_limit  0, or the caller's promise that every i and j is in [0, id_limit) -- an exclusive bound of the `orig` ids the
+ *             tables were built with (the larger cohort's size when they are row numbers): fewer key bits to sort above
+ *             8192 records.  The records are rebuilt from the narrowed keys, so an id outside the range comes back
+ *             truncated: pass 0 unless the bound is known (negative ids need 0). */
 int nsm_sort_hits(nsm_hit* hits, nsm_hit* scratch, uint64_t capacity, const unsigned long long* hit_count,
                   uint64_t n_hint, uint32_t id_limit, void* stream);
 

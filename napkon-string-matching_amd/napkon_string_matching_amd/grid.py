@@ -154,7 +154,9 @@ def jaccard_raw_grid(
             ls, rs, float(threshold), flags, buf.records.data_ptr(), buf.capacity, buf.count.data_ptr(), stream
         )
 
-    return run_grid(launch, left.ids.device, capacity, "nsm_jaccard_raw_grid", id_limit=max(left.n, right.n))
+    # (0 = unknown on either side: the sort keeps all 32 bits of the ids)
+    id_limit = max(left.id_limit, right.id_limit) if left.id_limit and right.id_limit else 0
+    return run_grid(launch, left.ids.device, capacity, "nsm_jaccard_raw_grid", id_limit=id_limit)
 
 
 def indel_raw_grid(

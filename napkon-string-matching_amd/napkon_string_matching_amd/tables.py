@@ -41,6 +41,17 @@ class IrregularLevels(NotImplementedError):
     host routes such items -- and only them -- through the general kernels (wide.py)."""
 
 
+def _id_limit(orig, n: int) -> int:
+    """An exclusive upper bound of the ids a table reports: ``n`` for the default ``arange(n)``, else max(orig) + 1;
+    0 (= unknown: the sort keeps all 32 bits) when an id is negative."""
+    if orig is None:
+        return int(n)
+    o = np.asarray(orig)
+    if o.size == 0:
+        return int(n)
+    return 0 if int(o.min()) < 0 else int(o.max()) + 1
+
+
 def inverted_index(ids: np.ndarray, cnt: np.ndarray, vocab: int, seg: Optional[np.ndarray] = None):
     """The global inverted index of a set table (include/nsm_hip.h: post / post_start / post_sq), the numpy way --
     what ``nsm_build_set_table`` builds on the GPU, byte for byte.  ``ids`` [n][W] (RAW: ascending per row), ``cnt`` [n];
@@ -225,6 +236,7 @@ class SetTable:
     post_start: Optional[torch.Tensor] = None
     vocab: int = 0
     post_sq: Tuple[int, ...] = (0, 0, 0, 0, 0)
+    id_limit: int = 0  # every ``orig`` entry is below it (the sort's key width, nsm_sort_hits); 0 = unknown
 
     # ------------------------------------------------------------------ builders
     @classmethod
@@ -417,6 +429,7 @@ class SetTable:
             ids.sort(axis=1)
         ids[np.arange(width, dtype=np.int32)[None, :] >= cnt[:, None]] = pad
         base = np.arange(n, dtype=np.int32) if orig is None else np.asarray(orig, dtype=np.int32)
+        id_limit = _id_limit(orig, n)  # (n = the caller's items here; a partition changes it below)
         seg = seg_start = None
         mode = category_mode if (nlev is not None and cat is not None) else _lib.CAT_NONE
         if cat is not None:
@@ -491,6 +504,7 @@ class SetTable:
             seg=None if seg is None else _dev(seg, device),
             seg_start=None if seg_start is None else _dev(seg_start, device),
             category_mode=mode if nlev is not None else None,
+            id_limit=id_limit,
         )
 
     @classmethod
@@ -545,6 +559,7 @@ class SetTable:
         if st.n != rows:
             raise _lib.NsmLibraryError(f"nsm_build_set_table built {st.n} rows, expected {rows}")
         t.post_sq = tuple(int(v) for v in st.post_sq)
+        t.id_limit = _id_limit(orig, n)
         for col in ("ids", "cnt", "sig", "sig2", "orig", "nlev", "plen", "cat", "filt", "seg"):
             if getattr(t, col) is not None:
                 setattr(t, col, getattr(t, col)[:rows])

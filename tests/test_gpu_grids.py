@@ -139,6 +139,29 @@ def test_jaccard_raw_global_index(dev, width, kmax, vocab, n_left, n_right):
         _same_hits(grid.jaccard_raw_grid(lt0, rt0, 0.0, index=True), want0)
 
 
+def test_jaccard_raw_caller_ids_beyond_row_count(dev):
+    """Tables built with caller ids (``orig``) far above the row count -- a shard of a larger cohort -- through the radix
+    sort (> 8192 hits): the sort's key width comes from the tables' id bound, not from their row counts, and ids with the
+    sign bit set fall back to full-width keys."""
+    from napkon_string_matching_amd import grid, tables
+    from oracle import native
+
+    rng = random.Random(77)
+    left = _rand_padded(rng, 300, 16, 40, 12, allow_empty=False)
+    right = _rand_padded(rng, 400, 16, 40, 12, allow_empty=False)
+    want = native.jaccard_raw(native.csr_from_padded(left), native.csr_from_padded(right), 0.2, cap=1 << 20)
+    assert len(want) > 8192
+    for lo, ro in ((5_000_000, 2_000_000_000), (0, 70_000), (-7, 3)):
+        li = np.arange(300, dtype=np.int32) * 3 + lo
+        ri = np.arange(400, dtype=np.int32) + ro
+        lt = tables.SetTable.from_padded(left, "left", dev, width=16, orig=li)
+        rt = tables.SetTable.from_padded(right, "right", dev, width=16, orig=ri)
+        assert lt.id_limit == (0 if lo < 0 else int(li.max()) + 1) and rt.id_limit == int(ri.max()) + 1
+        got = grid.jaccard_raw_grid(lt, rt, 0.2)
+        exp = sorted(((s, int(li[i]), int(ri[j])) for s, i, j in want), key=lambda h: (-h[0], h[1], h[2]))
+        assert [(h[0], h[1], h[2]) for h in got.as_tuples()] == exp
+
+
 def test_jaccard_raw_c2_shaped_low_threshold(dev):
     """configs[1]'s generator at the API's default threshold 0.1 (types/comparable_data.py:74), 20k x 20k: the
     index kernel against the exhaustive matrix kernel, and the collision-crafted ids of the signature test."""
