@@ -215,8 +215,8 @@ class Workload:
             torch.cuda.synchronize(device)
             self.encode_h2d_seconds = time.perf_counter() - t_enc
             self.launch_fn = self.lib.nsm_indel_raw_grid
-            self.kernel = "indel_raw_kernel"
-            self.kernel_match, self.kernel_match_exhaustive = "indel_raw_kernel<true>", "indel_raw_kernel<false>"
+            self.kernel = "indel_raw_coarse_kernel (two-stage histogram filter)"
+            self.kernel_match, self.kernel_match_exhaustive = "indel_raw_coarse_kernel", "indel_raw_kernel<false>"
             self.dtype = "u64"
             self.label = f"C3: {n}x{m} strings/GPU (len U[16,64], 37 symbols), fuzzy_match RAW, threshold {self.threshold}"
         self.n, self.m = n, m

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define NSM_ABI_VERSION 4
+#define NSM_ABI_VERSION 5
 
 #define NSM_E_BADARG 10001   /* inconsistent sizes / unsupported width */
 #define NSM_E_UNSUPPORTED 10002
@@ -129,6 +129,12 @@ typedef struct nsm_set_table {
  *                                   (len_start[0] = 0, len_start[stride+1] = n); required by the RAW grid
  *   hist  device uint8 [n][32]      symbol histogram: hist[r][b] = number of code units c of row r
  *                                   with (c & 31) == b; optional (NULL: no histogram prune)
+ *   hist16 device uint8 [n][16]     (ABI 5) the same histogram over 16 buckets: hist16[r][b] = min(255, hist[r][b] +
+ *                                   hist[r][b + 16]); optional.  With it on BOTH sides the RAW grid of 64-unit strings
+ *                                   filters in two stages: 16 buckets for every pair (half the arithmetic and half the
+ *                                   bytes of the 32-bucket test, which can only pass more pairs), 32 buckets for the
+ *                                   pairs that pass (csrc/indel_raw_coarse.hpp); the hits are the same either way.
+ *                                   16-byte aligned (a row is read as one 128-bit word)
  */
 typedef struct nsm_str_table {
   const uint8_t* codes;
@@ -140,6 +146,7 @@ typedef struct nsm_str_table {
   int32_t stride;   /* 64, 128, 256 or 512 code units per row (1, 2, 4 or 8 words of the bit-parallel LCS),
                        the same on both sides of a grid; anything else: NSM_E_UNSUPPORTED */
   int32_t alphabet; /* number of distinct code units, <= 255 */
+  const uint8_t* hist16;
 } nsm_str_table;
 
 /* Items whose levels are rows of a nsm_str_table (levels mode of fuzzy_match).
@@ -193,6 +200,8 @@ typedef struct nsm_level_items {
                               no fallback, no hit is written; the workspace's queue counters (words 2 ..) then hold the number
                               of pairs that outlive step 1 (they keep counting past the queue's capacity).  A host probes a
                               SAMPLE of the left rows this way and sizes / routes the real call from the count */
+#define NSM_FLAG_ONE_STAGE 1024u /* nsm_indel_raw_grid: the 32-bucket histogram test for every pair even when both tables carry
+                                    hist16 (A/B runs, tests) */
 #define NSM_FLAG_WAVE_WIDE 2u /* nsm_indel_levels_grid: score every step wave-wide (no block-cooperative
                                  parking of the surviving pairs); same hits, kept for A/B runs and tests */
 
@@ -287,7 +296,7 @@ int nsm_build_set_table(const int32_t* ids_in, int32_t n, int32_t width_in, int3
                         uint32_t flags, nsm_set_table* out, void* stream);
 
 /* Code-unit string table.  codes_in device uint8 [n][out->stride] (positions >= len are ignored and rewritten to
- * the pad code out->alphabet), len_in device int32 [n]. */
+ * the pad code out->alphabet), len_in device int32 [n].  The hist and hist16 columns are filled when out provides them. */
 int nsm_build_str_table(const uint8_t* codes_in, const int32_t* len_in, const int32_t* orig_in, int32_t n, uint32_t flags,
                         nsm_str_table* out, void* stream);
 

@@ -313,22 +313,27 @@ __global__ void post_keys_kernel(const int32_t* __restrict__ ids, const int32_t*
   vals[s] = val;
 }
 
-// post_start[q] = index of the first sorted entry whose (id * 5 + class) is >= q, for q in [0, 5 vocab]
+// post_start[q] = index of the first sorted entry whose (id * 5 + class) is >= q, for q in [0, 5 vocab] = the number of
+// entries whose class key is below q.  The last entry e of every run of equal class keys k writes e + 1 to slot k + 1 of the
+// zeroed array; a forward MAX-scan then fills the slots of the empty (id, class) lists -- most of the key space of a
+// partitioned levels table, where one thread walking a gap took 41 ms per table (profiles/pmc_c5.json of round 4).
 __global__ void post_bounds_kernel(const unsigned long long* __restrict__ keys, long long n, int vocab, unsigned long long key_mask,
                                    int32_t* __restrict__ post_start, unsigned long long* __restrict__ vals) {
   const long long e = static_cast<long long>(blockIdx.x) * kThreads + threadIdx.x;
-  if (e > n) return;
+  if (e >= n) return;
   const long long sentinel = 5ll * vocab;
   auto ckey = [&](long long at) -> long long {
-    if (at < 0) return -1;
     if (at >= n) return sentinel;
     const unsigned long long k = keys[at];
     if ((k & key_mask) == key_mask) return sentinel;  // an unused slot (all ones in the sorted bits)
     return static_cast<long long>(k >> 8) * 5 + post_class(static_cast<int>(k & 0xffu));
   };
-  const long long cur = ckey(e), prev = ckey(e - 1);
-  for (long long q = prev + 1; q <= cur; ++q) post_start[q] = static_cast<int32_t>(e);
-  if (e < n && cur == sentinel) vals[e] = 0ull;  // (the tail stays zero whatever the sort left there)
+  const long long cur = ckey(e);
+  if (cur == sentinel) {
+    vals[e] = 0ull;  // (the tail stays zero whatever the sort left there)
+    return;
+  }
+  if (ckey(e + 1) != cur) post_start[cur + 1] = static_cast<int32_t>(e + 1);
 }
 
 __global__ void post_stats_kernel(const int32_t* __restrict__ post_start, int vocab, unsigned long long* __restrict__ sq) {
@@ -363,8 +368,8 @@ __global__ void str_keys_kernel(const int32_t* __restrict__ len_in, int n, int s
 __global__ void str_gather_kernel(const int32_t* __restrict__ perm, int n, int stride, int alphabet,
                                   const uint8_t* __restrict__ codes_in, const int32_t* __restrict__ len_in,
                                   const int32_t* __restrict__ orig_in, uint8_t* __restrict__ codes, int32_t* __restrict__ len,
-                                  int32_t* __restrict__ orig, uint8_t* __restrict__ hist, uint32_t* __restrict__ len_class,
-                                  Status* st) {
+                                  int32_t* __restrict__ orig, uint8_t* __restrict__ hist, uint8_t* __restrict__ hist16,
+                                  uint32_t* __restrict__ len_class, Status* st) {
   __shared__ uint8_t s_hist[kThreads][36];  // 36-byte rows: the threads of a wavefront spread over the banks
   const int r = blockIdx.x * kThreads + threadIdx.x;
   if (r >= n) return;
@@ -398,6 +403,11 @@ __global__ void str_gather_kernel(const int32_t* __restrict__ perm, int n, int s
     for (int q = 0; q < 8; ++q)
       ho[q] = static_cast<uint32_t>(h[4 * q]) | (static_cast<uint32_t>(h[4 * q + 1]) << 8) |
               (static_cast<uint32_t>(h[4 * q + 2]) << 16) | (static_cast<uint32_t>(h[4 * q + 3]) << 24);
+  }
+  if (hist16) {  // 16 buckets: bucket b and bucket b + 16 together, saturating like the 32-bucket counts
+    uint32_t* ho = reinterpret_cast<uint32_t*>(hist16 + static_cast<size_t>(r) * 16);
+    auto both = [&](int b) -> uint32_t { return static_cast<uint32_t>(min(255, static_cast<int>(h[b]) + static_cast<int>(h[b + 16]))); };
+    for (int q = 0; q < 4; ++q) ho[q] = both(4 * q) | (both(4 * q + 1) << 8) | (both(4 * q + 2) << 16) | (both(4 * q + 3) << 24);
   }
   if (len_class) len_class[r] = static_cast<uint32_t>(stride - L);
 }
@@ -622,8 +632,21 @@ extern "C" int nsm_build_set_table(const int32_t* ids_in, int32_t n, int32_t wid
                                     static_cast<unsigned>(bits), stream);
       if (e != hipSuccess) return hip_status(e, "radix_sort_pairs (postings)");
     }
-    hipLaunchKernelGGL(post_bounds_kernel, blocks_for(slots + 1), dim3(kThreads), 0, stream, keys_sorted, slots,
-                       static_cast<int>(n_keys), key_mask, const_cast<int32_t*>(out->post_start), post);
+    int32_t* post_start = const_cast<int32_t*>(out->post_start);
+    const size_t n_bounds = static_cast<size_t>(5 * n_keys + 1);
+    (void)hipMemsetAsync(post_start, 0, n_bounds * sizeof(int32_t), stream);
+    if (slots > 0)
+      hipLaunchKernelGGL(post_bounds_kernel, blocks_for(slots), dim3(kThreads), 0, stream, keys_sorted, slots,
+                         static_cast<int>(n_keys), key_mask, post_start, post);
+    {
+      size_t bytes = 0;
+      hipError_t e = rocprim::inclusive_scan(nullptr, bytes, post_start, post_start, n_bounds, rocprim::maximum<int32_t>(), stream);
+      if (e != hipSuccess) return hip_status(e, "inclusive_scan (posting bounds, size)");
+      char* temp = sc.get<char>(bytes);
+      if (sc.failed) return hip_status(hipErrorOutOfMemory, "builder scratch");
+      e = rocprim::inclusive_scan(temp, bytes, post_start, post_start, n_bounds, rocprim::maximum<int32_t>(), stream);
+      if (e != hipSuccess) return hip_status(e, "inclusive_scan (posting bounds)");
+    }
     hipLaunchKernelGGL(post_stats_kernel, blocks_for(n_keys), dim3(kThreads), 0, stream, out->post_start, static_cast<int>(n_keys),
                        d_sq);
   }
@@ -675,7 +698,8 @@ extern "C" int nsm_build_str_table(const uint8_t* codes_in, const int32_t* len_i
     }
     hipLaunchKernelGGL(str_gather_kernel, blocks_for(n), dim3(kThreads), 0, stream, perm, n, stride, out->alphabet, codes_in,
                        len_in, orig_in, const_cast<uint8_t*>(out->codes), const_cast<int32_t*>(out->len),
-                       const_cast<int32_t*>(out->orig), const_cast<uint8_t*>(out->hist), len_class, d_status);
+                       const_cast<int32_t*>(out->orig), const_cast<uint8_t*>(out->hist), const_cast<uint8_t*>(out->hist16), len_class,
+                       d_status);
   }
   if (sort) {
     if (int rc = class_starts(len_class, n, stride + 1, const_cast<int32_t*>(out->len_start), sc)) return rc;

@@ -67,15 +67,78 @@ __device__ __forceinline__ unsigned long long add64(unsigned long long a, unsign
   return d;
 }
 
+// The wave's match-mask table of pattern row i: one ds_write_b64 sweep to clear, ONE ds_or_b64 to set.  A narrow pattern
+// (<= 32 code units) stores its mask in BOTH halves of the entry (see the kernel's notes on LDS banks).
+__device__ __forceinline__ void raw_build_masks(unsigned long long* pm, int pm_stride, const uint8_t* __restrict__ lcodes, int i,
+                                                int la, bool wide, int lane) {
+  for (int c = lane; c < pm_stride; c += kWave) pm[c] = 0ull;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (lane < la) {
+    const unsigned c = lcodes[static_cast<size_t>(i) * 64 + lane];
+    atomicOr(&pm[c], wide ? (1ull << lane) : ((1ull << lane) | (1ull << (32 + lane))));
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// LCS of the pattern whose match masks are in the wave's table (LDS byte offset pm_base) against text row j, lean form of
+// the pruning kernels: 16 code units of the text per global load, addresses computed on the fly, no register outlives it.
+__device__ __forceinline__ int raw_lcs_lean(const uint8_t* __restrict__ rcodes, int j, uint32_t pm_base, bool wide, int npairs) {
+  const uint4* tp = reinterpret_cast<const uint4*>(rcodes + static_cast<size_t>(j) * 64);
+  const uint32_t hsel = wide ? 0u : 4u;
+  const int nchars = 2 * npairs;
+  uint32_t v32 = ~0u;
+  unsigned long long v64 = ~0ull;
+  for (int q = 0; q < 4; ++q) {
+    if (q * 16 >= nchars) break;
+    const uint4 t4 = tp[q];
+    const uint32_t w[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      uint32_t addr[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t c = (w[e] >> (8 * k)) & 0xffu;
+        addr[k] = pm_base + 8 * c + (((c >> 4) & 1u) ? hsel : 0u);
+      }
+      if (!wide) {
+        uint32_t m[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m[k] = lds_load<uint32_t>(addr[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v32 = lcs_step32(v32, m[k]);
+      } else {
+        unsigned long long m[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m[k] = lds_load<unsigned long long>(addr[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v64 = lcs_step64(v64, m[k]);
+      }
+    }
+  }
+  return wide ? 64 - __popcll(v64) : 32 - __popc(v32);
+}
+
 #ifndef NSM_C3_OCC
 #define NSM_C3_OCC
 #endif
+// right tiles (of 64 strings) per wavefront of the pruning kernel: every histogram of a left row that the wave fetches
+// with its scalar loads is tested against T x 64 right strings (section 4.3 of DESIGN.md: the histogram loop waits for
+// its scalar loads, not for the VALU)
+#ifndef NSM_C3_TILES
+#define NSM_C3_TILES 2
+#endif
+template <bool PRUNE>
+constexpr int c3_tiles() { return PRUNE ? NSM_C3_TILES : 1; }
+
 template <bool PRUNE>
 __global__ __launch_bounds__(kBlock) NSM_C3_OCC void indel_raw_kernel(
     const uint8_t* __restrict__ lcodes, const int32_t* __restrict__ llen, const int32_t* __restrict__ lstart,
     const int32_t* __restrict__ lorig, const uint32_t* __restrict__ lhist, const uint8_t* __restrict__ rcodes,
     const int32_t* __restrict__ rlen, const int32_t* __restrict__ rorig, const uint32_t* __restrict__ rhist,
     nsm_hit* __restrict__ hits, unsigned long long* __restrict__ count, const IndelRawParams p) {
+  constexpr int T = c3_tiles<PRUNE>();
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_mem[];
   // layout: [wave][pm_stride] match masks, then the lcsmin bytes
   uint8_t* s_lcsmin = reinterpret_cast<uint8_t*>(s_mem + kWavesPerBlock * p.pm_stride);
@@ -84,18 +147,22 @@ __global__ __launch_bounds__(kBlock) NSM_C3_OCC void indel_raw_kernel(
 
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
-  const int tile = blockIdx.x * kWavesPerBlock + wave;
-  if (tile * kWave >= p.n_right) return;
-  const int j = tile * kWave + lane;
-  const bool valid = j < p.n_right;
-  const int jc = valid ? j : p.n_right - 1;
+  const int tile0 = (blockIdx.x * kWavesPerBlock + wave) * T;  // the wave's tiles: tile0 .. tile0 + T - 1
+  if (tile0 * kWave >= p.n_right) return;
+  bool valid[T];
+  int jc[T], lbj[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int j = (tile0 + t) * kWave + lane;
+    valid[t] = j < p.n_right;
+    jc[t] = valid[t] ? j : p.n_right - 1;
+    lbj[t] = valid[t] ? rlen[jc[t]] : 0;
+  }
 
   unsigned long long* pm = s_mem + wave * p.pm_stride;
   const uint32_t pm_base = static_cast<uint32_t>(wave * p.pm_stride * 8);  // s_mem starts at LDS offset 0
 
-  // text as LDS addresses of the symbols' masks: two 16-bit fields per VGPR.  With the prune on,
-  // LCS rows are rare (< 0.1 % of the rows a wave visits on C3), so the 32 registers are rebuilt
-  // per LCS row instead of being kept live across the histogram loop (occupancy 4 -> 8 waves/SIMD).
+  // text as LDS addresses of the symbols' masks: two 16-bit fields per VGPR.
   // Patterns <= 32 read their masks with ds_read_b32: at the table's 8-byte stride those reads only touch
   // the even LDS banks, symbols c and c + 16 collide (37 symbols over 16 banks: half of the exhaustive kernel's
   // LDS cycles were bank conflicts, profiles/r02_before_c3_sq_pmc.txt).  The mask of a narrow pattern is
@@ -110,7 +177,7 @@ __global__ __launch_bounds__(kBlock) NSM_C3_OCC void indel_raw_kernel(
   uint32_t taddr[PRUNE ? 1 : 32];
   auto build_taddr = [&](bool narrow) {
     if constexpr (!PRUNE) {
-      const uint4* tp = reinterpret_cast<const uint4*>(rcodes + static_cast<size_t>(jc) * 64);
+      const uint4* tp = reinterpret_cast<const uint4*>(rcodes + static_cast<size_t>(jc[0]) * 64);
       const uint32_t hsel = narrow ? 4u : 0u;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -128,15 +195,16 @@ __global__ __launch_bounds__(kBlock) NSM_C3_OCC void indel_raw_kernel(
     }
   };
   int taddr_narrow = -1;  // which variant the registers hold (exhaustive mode keeps them across rows)
-  const int lbj = valid ? rlen[jc] : 0;
-  const int jorig = rorig[jc];
-  const int npairs = (wave_first(lbj) + 1) >> 1;  // sorted descending: lane 0 has the longest text
-  uint32_t hr[8];
+  const int npairs = (wave_first(lbj[0]) + 1) >> 1;  // sorted descending: lane 0 of the first tile has the longest text
+  uint32_t hr[T][8];
   if (PRUNE) {
-    const uint4* hp = reinterpret_cast<const uint4*>(rhist + static_cast<size_t>(jc) * 8);
-    const uint4 h0 = hp[0], h1 = hp[1];
-    hr[0] = h0.x; hr[1] = h0.y; hr[2] = h0.z; hr[3] = h0.w;
-    hr[4] = h1.x; hr[5] = h1.y; hr[6] = h1.z; hr[7] = h1.w;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const uint4* hp = reinterpret_cast<const uint4*>(rhist + static_cast<size_t>(jc[t]) * 8);
+      const uint4 h0 = hp[0], h1 = hp[1];
+      hr[t][0] = h0.x; hr[t][1] = h0.y; hr[t][2] = h0.z; hr[t][3] = h0.w;
+      hr[t][4] = h1.x; hr[t][5] = h1.y; hr[t][6] = h1.z; hr[t][7] = h1.w;
+    }
   }
   uint32_t lowmask = 0xffffu;  // kept in a VGPR: v_and with a VGPR operand issues at full rate
   asm volatile("" : "+v"(lowmask));
@@ -144,58 +212,11 @@ __global__ __launch_bounds__(kBlock) NSM_C3_OCC void indel_raw_kernel(
   const int i0 = blockIdx.y * p.rows_per_chunk;
   const int i1 = min(p.n_left, i0 + p.rows_per_chunk);
 
-  // the wave's match-mask table of pattern row i: one ds_write_b64 sweep to clear, one ds_or_b64 to set
-  auto build_masks = [&](int i, int la, bool wide) {
-    for (int c = lane; c < p.pm_stride; c += kWave) pm[c] = 0ull;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (lane < la) {
-      const unsigned c = lcodes[static_cast<size_t>(i) * 64 + lane];
-      atomicOr(&pm[c], wide ? (1ull << lane) : ((1ull << lane) | (1ull << (32 + lane))));  // narrow: both halves
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  };
+  auto build_masks = [&](int i, int la, bool wide) { raw_build_masks(pm, p.pm_stride, lcodes, i, la, wide, lane); };
+  auto lcs_lean = [&](int t, bool wide) -> int { return raw_lcs_lean(rcodes, jc[t], pm_base, wide, npairs); };
 
-  // ---- LCS of pattern row i (length la, match masks built here) against the lane's text
+  // ---- exhaustive kernel: LCS of pattern row i (length la, match masks built here) against the lane's text
   auto lcs_row = [&](int i, int la, bool wide) -> int {
-    if constexpr (PRUNE) {
-      // lean form: 16 code units of the text per global load, addresses computed on the fly
-      build_masks(i, la, wide);
-      const uint4* tp = reinterpret_cast<const uint4*>(rcodes + static_cast<size_t>(jc) * 64);
-      const uint32_t hsel = wide ? 0u : 4u;
-      const int nchars = 2 * npairs;
-      uint32_t v32 = ~0u;
-      unsigned long long v64 = ~0ull;
-      for (int q = 0; q < 4; ++q) {
-        if (q * 16 >= nchars) break;
-        const uint4 t4 = tp[q];
-        const uint32_t w[4] = {t4.x, t4.y, t4.z, t4.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          uint32_t addr[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const uint32_t c = (w[e] >> (8 * k)) & 0xffu;
-            addr[k] = pm_base + 8 * c + (((c >> 4) & 1u) ? hsel : 0u);
-          }
-          if (!wide) {
-            uint32_t m[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) m[k] = lds_load<uint32_t>(addr[k]);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v32 = lcs_step32(v32, m[k]);
-          } else {
-            unsigned long long m[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) m[k] = lds_load<unsigned long long>(addr[k]);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v64 = lcs_step64(v64, m[k]);
-          }
-        }
-      }
-      return wide ? 64 - __popcll(v64) : 32 - __popc(v32);
-    }
     if (taddr_narrow != static_cast<int>(!wide)) {
       build_taddr(!wide);
       taddr_narrow = static_cast<int>(!wide);
@@ -246,23 +267,36 @@ __global__ __launch_bounds__(kBlock) NSM_C3_OCC void indel_raw_kernel(
     const int b = min(i1, lstart[c + 1]);
     if (a >= b) continue;
     const int la = 64 - c;
-    int need;
-    if (la == 0 || lbj == 0) need = p.zero_need;
-    else need = s_lcsmin[la + lbj];
-    if (!valid) need = kNever;
+    int need[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      if (la == 0 || lbj[t] == 0) need[t] = p.zero_need;
+      else need[t] = s_lcsmin[la + lbj[t]];
+      if (!valid[t]) need[t] = kNever;
+    }
     const bool wide = la > 32;
-    if (PRUNE) {
+    if constexpr (PRUNE) {
       // exact length filter, per class: LCS <= min(la, lb)
-      const bool fits = min(la, lbj) >= need;
-      if (!__any(fits)) continue;
+      bool fits[T], some = false;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        fits[t] = min(la, lbj[t]) >= need[t];
+        some = some || fits[t];
+      }
+      if (!__any(some)) continue;
       // exact histogram filter, per row: LCS <= sum_c min(hA[c], hB[c]) = (la + lb - L1) / 2 over 32
       // symbol buckets, i.e. the row can only hit if L1 <= la + lb - 2 * lcsmin
-      const int limit = fits ? la + lbj - 2 * need : -1;
-      auto score_row = [&](int i) {
-        const int lcs = lcs_row(i, la, wide);
-        const bool hit = lcs >= need;
-        if (__any(hit)) {
-          if (hit) emit_hit(hits, p.cap, count, indel_score(la, lbj, lcs), lorig[i], jorig);
+      // `who`: bit t set = this lane's string of tile t passed the histogram filter for row i
+      auto score_row = [&](int i, uint32_t who) {
+        build_masks(i, la, wide);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          if (!__any((who >> t) & 1u)) continue;
+          const int lcs = lcs_lean(t, wide);
+          const bool hit = lcs >= need[t];
+          if (__any(hit)) {
+            if (hit) emit_hit(hits, p.cap, count, indel_score(la, lbj[t], lcs), lorig[i], rorig[jc[t]]);
+          }
         }
       };
       // 4 rows per iteration: their 32 histogram dwords arrive with two s_load_dwordx16 issued
@@ -270,7 +304,13 @@ __global__ __launch_bounds__(kBlock) NSM_C3_OCC void indel_raw_kernel(
       // exactly when L1 <= limit; one full-rate v_or per row folds the signs into the batch's verdict
       // (the scalar unit is shared by the CU's 4 SIMDs, keep it idle; v_cmp + v_addc per row cost
       // two half-rate ops).
-      const uint32_t seed = static_cast<uint32_t>(-(limit + 1));
+      int limit[T];
+      uint32_t seed[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        limit[t] = fits[t] ? la + lbj[t] - 2 * need[t] : -1;
+        seed[t] = static_cast<uint32_t>(-(limit[t] + 1));
+      }
       const uint32_t* __restrict__ hp = lhist + static_cast<size_t>(a) * 8;
       int i = a;
       // (Tried on top, same box, kernel ms against 6.52: a software pipeline over two scalar register sets of 2 rows each --
@@ -284,44 +324,67 @@ __global__ __launch_bounds__(kBlock) NSM_C3_OCC void indel_raw_kernel(
         uint32_t h[8 * BATCH];
 #pragma unroll
         for (int q = 0; q < 8 * BATCH; ++q) h[q] = hp[q];
-        int margin[BATCH];
+        int margin[T][BATCH];
         int any_pass = 0;  // sign bit set when some row of the batch may reach the threshold
 #pragma unroll
         for (int r = 0; r < BATCH; ++r) {
-          uint32_t l1 = seed;
 #pragma unroll
-          for (int q = 0; q < 8; ++q) l1 = __builtin_amdgcn_sad_u8(h[8 * r + q], hr[q], l1);
-          margin[r] = static_cast<int>(l1);
-          any_pass |= margin[r];
+          for (int t = 0; t < T; ++t) {
+            uint32_t l1 = seed[t];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) l1 = __builtin_amdgcn_sad_u8(h[8 * r + q], hr[t][q], l1);
+            margin[t][r] = static_cast<int>(l1);
+            any_pass |= margin[t][r];
+          }
         }
         if (__any(any_pass < 0)) {  // rare
-          uint32_t cand = 0;
+          uint32_t cand[T];
 #pragma unroll
-          for (int r = 0; r < BATCH; ++r) cand |= margin[r] < 0 ? (1u << r) : 0u;
-          for (int r = 0; r < BATCH; ++r)
-            if (__any((cand >> r) & 1u)) score_row(i + r);
+          for (int t = 0; t < T; ++t) {
+            cand[t] = 0;
+#pragma unroll
+            for (int r = 0; r < BATCH; ++r) cand[t] |= margin[t][r] < 0 ? (1u << r) : 0u;
+          }
+          for (int r = 0; r < BATCH; ++r) {
+            uint32_t who = 0;
+#pragma unroll
+            for (int t = 0; t < T; ++t) who |= ((cand[t] >> r) & 1u) << t;
+            if (__any(who != 0u)) score_row(i + r, who);
+          }
         }
       }
       for (; i < b; ++i, hp += 8) {
-        uint32_t l1 = 0;
+        uint32_t who = 0;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) l1 = __builtin_amdgcn_sad_u8(hp[q], hr[q], l1);
-        if (__any(static_cast<int>(l1) <= limit)) score_row(i);
+        for (int t = 0; t < T; ++t) {
+          uint32_t l1 = 0;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) l1 = __builtin_amdgcn_sad_u8(hp[q], hr[t][q], l1);
+          who |= (static_cast<int>(l1) <= limit[t] ? 1u : 0u) << t;
+        }
+        if (__any(who != 0u)) score_row(i, who);
       }
     } else {
       for (int i = a; i < b; ++i) {
         const int lcs = lcs_row(i, la, wide);
-        const bool hit = lcs >= need;
+        const bool hit = lcs >= need[0];
         if (__any(hit)) {
-          if (hit) emit_hit(hits, p.cap, count, indel_score(la, lbj, lcs), lorig[i], jorig);
+          if (hit) emit_hit(hits, p.cap, count, indel_score(la, lbj[0], lcs), lorig[i], rorig[jc[0]]);
         }
       }
     }
   }
 }
 
+}  // namespace nsm
+#include "indel_raw_coarse.hpp"
+namespace nsm {
+
 static int pick_rows_per_chunk(int n_left, int n_tiles) {
-  const long long want_waves = 16ll * 256 * 32;
+#ifndef NSM_C3_WANT_WAVES
+#define NSM_C3_WANT_WAVES (16ll * 256 * 32)
+#endif
+  const long long want_waves = NSM_C3_WANT_WAVES;
   long long chunks = (want_waves + n_tiles - 1) / (n_tiles > 0 ? n_tiles : 1);
   if (chunks < 1) chunks = 1;
   long long rows = (n_left + chunks - 1) / chunks;
@@ -386,7 +449,31 @@ extern "C" int nsm_indel_raw_grid(const nsm_str_table* left, const nsm_str_table
       }
     }
   }
-  const int n_tiles = (right->n + kWave - 1) / kWave;
+  const bool prune = (flags & NSM_FLAG_PRUNE) && left->hist && right->hist;
+  if (prune && left->hist16 && right->hist16 && !(flags & NSM_FLAG_ONE_STAGE)) {
+    if ((reinterpret_cast<uintptr_t>(left->hist16) | reinterpret_cast<uintptr_t>(right->hist16)) & 15u) {
+      set_error("nsm_indel_raw_grid: hist16 must be 16-byte aligned (rows are read as one 128-bit word)");
+      return NSM_E_BADARG;
+    }
+    // both tables carry the 16-bucket histograms: the two-stage filter (indel_raw_coarse.hpp)
+    constexpr int T = NSM_C3C_TILES;
+    const int n_tiles = ((right->n + kWave - 1) / kWave + T - 1) / T;
+    p.rows_per_chunk = pick_rows_per_chunk(left->n, n_tiles);
+    dim3 grid((n_tiles + kWavesPerBlock - 1) / kWavesPerBlock, (left->n + p.rows_per_chunk - 1) / p.rows_per_chunk);
+    if (grid.y > 65535) {
+      p.rows_per_chunk = (left->n + 65534) / 65535;
+      grid.y = (left->n + p.rows_per_chunk - 1) / p.rows_per_chunk;
+    }
+    hipLaunchKernelGGL((indel_raw_coarse_kernel<T, NSM_C3C_ROWS>), grid, dim3(kBlock), c3c_lds_bytes(T),
+                       static_cast<hipStream_t>(stream), left->codes, left->len, left->len_start, left->orig,
+                       reinterpret_cast<const uint32_t*>(left->hist), reinterpret_cast<const uint32_t*>(left->hist16), right->codes,
+                       right->len, right->orig, reinterpret_cast<const uint32_t*>(right->hist),
+                       reinterpret_cast<const uint32_t*>(right->hist16), hits, hit_count, p);
+    return hip_status(hipGetLastError(), "indel_raw_coarse_kernel launch");
+  }
+  // wavefronts along the right side: one per T tiles of 64 strings
+  const int tiles_per_wave = prune ? c3_tiles<true>() : 1;
+  const int n_tiles = ((right->n + kWave - 1) / kWave + tiles_per_wave - 1) / tiles_per_wave;
   p.rows_per_chunk = pick_rows_per_chunk(left->n, n_tiles);
   dim3 grid((n_tiles + kWavesPerBlock - 1) / kWavesPerBlock,
             (left->n + p.rows_per_chunk - 1) / p.rows_per_chunk);
@@ -398,7 +485,7 @@ extern "C" int nsm_indel_raw_grid(const nsm_str_table* left, const nsm_str_table
   hipStream_t s = static_cast<hipStream_t>(stream);
   const uint32_t* lh = reinterpret_cast<const uint32_t*>(left->hist);
   const uint32_t* rh = reinterpret_cast<const uint32_t*>(right->hist);
-  if ((flags & NSM_FLAG_PRUNE) && lh && rh)
+  if (prune)
     hipLaunchKernelGGL((indel_raw_kernel<true>), grid, dim3(kBlock), lds, s, left->codes, left->len,
                        left->len_start, left->orig, lh, right->codes, right->len, right->orig, rh, hits, hit_count, p);
   else

@@ -6,12 +6,13 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("NSM_HIP_LIBRARY", _HERE.parent / "csrc" / "libnsm_hip.so"))
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 FLAG_PRUNE = 1
 FLAG_WAVE_WIDE = 2  # nsm_indel_levels_grid without the block-cooperative parking (A/B runs, tests)
 FLAG_INDEX, FLAG_NO_INDEX = 4, 8  # nsm_jaccard_raw_grid: force / forbid the inverted-index kernels
 FLAG_TILE_INDEX = 64  # with FLAG_INDEX: the per-tile LDS index even when the right table carries a global one
 FLAG_RAW_SCORE = 32  # nsm_*_any_grid: the RAW plugin call instead of compare_terms
+FLAG_ONE_STAGE = 1024  # nsm_indel_raw_grid: the 32-bucket histogram test for every pair (no 16-bucket first stage)
 FLAG_SPLIT, FLAG_TILE, FLAG_PROBE = 128, 256, 512  # nsm_indel_levels_grid, one-word strings: force the split path / the tile kernel; scan only
 FLAG_PARK = 16  # nsm_indel_levels_grid, strings > 64 code units: the round-2 park kernel instead of the shared-tile kernel
 BUILD_PARTITION, BUILD_VALIDATE, BUILD_SORT = 1, 2, 4
@@ -59,6 +60,7 @@ class NsmStrTable(ctypes.Structure):
         ("n", ctypes.c_int32),
         ("stride", ctypes.c_int32),
         ("alphabet", ctypes.c_int32),
+        ("hist16", ctypes.c_void_p),
     ]
 
 

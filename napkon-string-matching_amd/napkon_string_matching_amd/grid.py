@@ -160,12 +160,15 @@ def jaccard_raw_grid(
 
 
 def indel_raw_grid(
-    left: StrTable, right: StrTable, threshold: float, prune: bool = True, capacity: Optional[int] = None
+    left: StrTable, right: StrTable, threshold: float, prune: bool = True, capacity: Optional[int] = None,
+    two_stage: bool = True,
 ) -> Hits:
-    """``fuzzy_match`` (QRatio/100 = Indel ratio after default_process) on one string per item."""
+    """``fuzzy_match`` (QRatio/100 = Indel ratio after default_process) on one string per item.
+    ``two_stage=False``: the 32-bucket histogram test for every pair even when both tables carry the 16-bucket
+    column (A/B runs, tests; same hits)."""
     lib = _lib.load()
     ls, rs = left.struct(), right.struct()
-    flags = _lib.FLAG_PRUNE if prune else 0
+    flags = (_lib.FLAG_PRUNE if prune else 0) | (0 if two_stage else _lib.FLAG_ONE_STAGE)
 
     def launch(buf: HitBuffer, stream: int) -> int:
         return lib.nsm_indel_raw_grid(

@@ -640,6 +640,9 @@ class StrTable:
     has_empty: bool
     hist: Optional[torch.Tensor] = None
     len_start: Optional[torch.Tensor] = None
+    # 16-bucket histogram (bucket b + bucket b + 16 of ``hist``): the first stage of the RAW grid's filter on 64-unit
+    # strings (include/nsm_hip.h, ABI 5); only sorted 64-unit tables carry it
+    hist16: Optional[torch.Tensor] = None
 
     @classmethod
     def from_codes(
@@ -672,12 +675,14 @@ class StrTable:
             live = np.arange(stride, dtype=np.int32)[None, :] < lengths[:, None]
             slot = (np.arange(n, dtype=np.int64)[:, None] * 32 + (codes & 31))[live]
             hist = np.bincount(slot, minlength=n * 32).reshape(n, 32)
+        hist16 = np.minimum(hist[:, :16] + hist[:, 16:], 255).astype(np.uint8) if (sort and stride == 64) else None
         hist = np.minimum(hist, 255).astype(np.uint8)
         # rows of length (stride - c) occupy [len_start[c], len_start[c + 1]) in the length-sorted table
         len_start = np.zeros(stride + 2, dtype=np.int32)
         len_start[1:] = np.cumsum(np.bincount(lengths, minlength=stride + 1)[: stride + 1][::-1])
         return cls(
             hist=_dev(hist[perm], device),
+            hist16=None if hist16 is None else _dev(hist16[perm], device),
             len_start=_dev(len_start, device) if sort else None,
             codes=_dev(codes[perm], device),
             len=_dev(lengths[perm], device),
@@ -701,6 +706,7 @@ class StrTable:
         t = cls(codes=new((cap, stride), torch.uint8), len=new(cap, torch.int32),
                 orig=new(cap, torch.int32), n=n, stride=stride, alphabet=alphabet,
                 has_empty=bool(n and int(lengths.min()) == 0), hist=new((cap, 32), torch.uint8),
+                hist16=new((cap, 16), torch.uint8) if (sort and stride == 64) else None,
                 len_start=new(stride + 2, torch.int32) if sort else None)
         d_codes, d_len = _dev(codes, dev), _dev(lengths, dev)
         d_orig = None if orig is None else _dev(np.asarray(orig, dtype=np.int32), dev)
@@ -718,6 +724,9 @@ class StrTable:
         t.orig[n:].zero_()
         t.hist[n:].zero_()
         t.codes, t.len, t.orig, t.hist = t.codes[:n], t.len[:n], t.orig[:n], t.hist[:n]
+        if t.hist16 is not None:
+            t.hist16[n:].zero_()
+            t.hist16 = t.hist16[:n]
         return t
 
     @classmethod
@@ -735,6 +744,7 @@ class StrTable:
             self.codes.data_ptr(), self.len.data_ptr(), self.orig.data_ptr(),
             None if self.len_start is None else self.len_start.data_ptr(),
             None if self.hist is None else self.hist.data_ptr(), self.n, self.stride, self.alphabet,
+            None if self.hist16 is None else self.hist16.data_ptr(),
         )
 
     def nbytes(self) -> int:

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
     # struct layouts must match the header (sizes on LP64)
     assert ctypes.sizeof(_lib.NsmHit) == 16
     assert ctypes.sizeof(_lib.NsmSetTable) == 12 * 8 + 4 * 4 + 2 * 8 + 5 * 8
-    assert ctypes.sizeof(_lib.NsmStrTable) == 5 * 8 + 3 * 4 + 4
+    assert ctypes.sizeof(_lib.NsmStrTable) == 5 * 8 + 3 * 4 + 4 + 8  # (ABI 5: hist16)
     assert ctypes.sizeof(_lib.NsmLevelItems) == 6 * 8 + 4 + 4
 
 

@@ -109,8 +109,9 @@ def test_str_table(dev, stride, sort):
     g = tables.StrTable.from_codes(codes, lengths, alphabet, dev, sort=sort)
     c = tables.StrTable.from_codes(codes, lengths, alphabet, "cpu", sort=sort)
     assert (g.n, g.stride, g.alphabet, g.has_empty) == (c.n, c.stride, c.alphabet, c.has_empty)
-    for col in ("codes", "len", "orig", "hist", "len_start"):
+    for col in ("codes", "len", "orig", "hist", "hist16", "len_start"):
         _same(getattr(g, col), getattr(c, col), col)
+    assert (c.hist16 is not None) == (sort and stride == 64)  # the 16-bucket column: RAW tables of 64-unit strings
     bad = codes.copy()
     bad[7, 0] = 200
     lengths[7] = 3

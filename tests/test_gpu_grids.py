@@ -281,6 +281,39 @@ def test_indel_raw_random(dev, alphabet, lo, hi, prune):
         got = grid.indel_raw_grid(lt, rt, thr, prune=prune, capacity=1 << 10)
         _same_hits(got, want, FUZZY_TOL)
         _same_hits(got, want)  # and in fact bit-exact
+        if prune and lt.hist16 is not None:  # the 32-bucket test for every pair (no 16-bucket first stage)
+            _same_hits(grid.indel_raw_grid(lt, rt, thr, two_stage=False, capacity=1 << 10), want)
+
+
+def test_indel_raw_two_stage_filter(dev):
+    """The two-stage histogram filter of the RAW grid on 64-unit strings (16 buckets for every pair, 32 buckets for the
+    pairs that pass, the LCS of the rest on the scalar unit) where its queue is busy: a 4-letter alphabet (most pairs pass
+    the coarse test, entries carry several pairs and go back on the stack), strings of every length incl. empty ones, more
+    right rows than two tiles per wave divide, thresholds down to 0 (every pair is a hit) -- against the oracle, the
+    one-stage kernel and the exhaustive kernel."""
+    from napkon_string_matching_amd import grid, tables
+    from oracle import native
+
+    rng = random.Random(4242)
+    for alphabet, n_left, n_right, thresholds in (("abcd", 700, 531, (0.0, 0.35, 0.6, 0.8, 1.0)),
+                                                  ("abcdefghijklmnopqrstuvwxyz0123456789 .", 900, 777, (0.3, 0.5, 0.7))):
+        left = _rand_strings(rng, n_left, alphabet, 0, 64)
+        right = _rand_strings(rng, n_right, alphabet, 0, 64)
+        for k in range(0, n_right, 5):  # near-duplicates: a left string with one code unit changed or dropped
+            src = left[rng.randrange(n_left)]
+            if src:
+                pos = rng.randrange(len(src))
+                right[k] = src[:pos] + (rng.choice(alphabet) if rng.random() < 0.5 else "") + src[pos + 1:]
+        lt, rt = tables.encode_strings(left, right, dev)
+        assert lt.stride == 64 and lt.hist16 is not None and rt.hist16 is not None
+        cp = lambda ss: native.csr([[ord(c) for c in s] for s in ss])
+        base = native.indel_raw(cp(left), cp(right), min(thresholds), cap=1 << 20)
+        for thr in thresholds:
+            want = [h for h in base if h[0] >= thr]  # (the oracle's list is ordered by score already)
+            assert len(want) > 0
+            _same_hits(grid.indel_raw_grid(lt, rt, thr), want)
+            _same_hits(grid.indel_raw_grid(lt, rt, thr, two_stage=False), want)
+            _same_hits(grid.indel_raw_grid(lt, rt, thr, prune=False), want)
 
 
 def test_indel_raw_c3_shaped(dev):
@@ -294,6 +327,7 @@ def test_indel_raw_c3_shaped(dev):
     assert len(want) >= 10
     for prune in (False, True):
         _same_hits(grid.indel_raw_grid(lt, rt, 0.8, prune=prune), want, FUZZY_TOL)
+    _same_hits(grid.indel_raw_grid(lt, rt, 0.8, two_stage=False), want, FUZZY_TOL)
 
 
 def test_indel_known_answers(dev):

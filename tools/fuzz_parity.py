@@ -155,8 +155,9 @@ def main():
             cp = lambda ss: native.csr([[ord(c) for c in s] for s in ss])
             want = native.indel_raw(cp(left), cp(right), thr, cap=1 << 18)
             prune = rng.random() < 0.7
-            check(grid.indel_raw_grid(lt, rt, thr, prune=prune), want,
-                  f"indel_raw hi={hi} |alphabet|={len(alphabet)} thr={thr} prune={prune} {n}x{m}")
+            two_stage = rng.random() < 0.7  # (64-unit tables: the 16-bucket first stage of the histogram filter, or not)
+            check(grid.indel_raw_grid(lt, rt, thr, prune=prune, two_stage=two_stage), want,
+                  f"indel_raw hi={hi} |alphabet|={len(alphabet)} thr={thr} prune={prune} two_stage={two_stage} {n}x{m}")
         else:
             ncat = rng.choice([0, 3, 6, 40, 64])
             mode = _lib.CAT_NONE if ncat == 0 else rng.choice([_lib.CAT_INTERSECT, _lib.CAT_INTERSECT_OR_BOTH_EMPTY])
