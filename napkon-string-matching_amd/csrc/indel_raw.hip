@@ -464,6 +464,10 @@ extern "C" int nsm_indel_raw_grid(const nsm_str_table* left, const nsm_str_table
       p.rows_per_chunk = (left->n + 65534) / 65535;
       grid.y = (left->n + p.rows_per_chunk - 1) / p.rows_per_chunk;
     }
+    if (p.rows_per_chunk > (1 << 15)) {  // (a stack entry keeps its row relative to the chunk in 15 bits)
+      set_error("nsm_indel_raw_grid: %d left rows per chunk", p.rows_per_chunk);
+      return NSM_E_UNSUPPORTED;
+    }
     hipLaunchKernelGGL((indel_raw_coarse_kernel<T, NSM_C3C_ROWS>), grid, dim3(kBlock), c3c_lds_bytes(T),
                        static_cast<hipStream_t>(stream), left->codes, left->len, left->len_start, left->orig,
                        reinterpret_cast<const uint32_t*>(left->hist), reinterpret_cast<const uint32_t*>(left->hist16), right->codes,

@@ -6,19 +6,20 @@
 // v_sad_u8.  On configs[2] it passes 1 % of the pairs -- far too many for a wave-wide second look (some lane of a row's 64
 // passes in 20 % of the rows), so the survivors are handled PER PAIR:
 //
-//   scan    per batch of 4 left rows (their 64 bytes of coarse histograms arrive with one s_load_dwordx16) and T right
-//           tiles: 4 v_sad_u8 per pair, the sign of the seeded sum shifted into a per-lane bit mask (v_alignbit);
+//   scan    per batch of R = 8 left rows (their 128 bytes of coarse histograms arrive with two s_load_dwordx16) and T = 2
+//           right tiles: 4 v_sad_u8 per pair, the sign of the seeded sum shifted into a per-lane bit mask (v_alignbit);
 //   stack   lanes whose mask is not empty push (batch, lane, mask) on the wave's LDS stack -- one ballot and one ds_write per
 //           BATCH, nothing per pair;
-//   drain   whenever the stack holds 128 entries, 64 at a time (64 of 64 lanes busy): lane = one entry, ONE of its pairs
-//           (an entry with more pairs goes back on the stack) -- the 32-bucket L1 of the pair (the left histogram gathered
-//           from global memory, the right one read from the tile's copy in LDS, 8 v_sad_u8: 1 % of the pairs), then, for the
-//           1e-5 that remain, the bit-parallel LCS wave-wide as in the one-stage kernel (the tile's lanes that survived for
-//           the row are told through an LDS flag each).  Entries carry their row, so the stack outlives the length classes
-//           and is emptied once, at the end.
+//   drain   whenever the stack holds more than 128 entries, 64 at a time (64 of 64 lanes busy): lane = one entry, ONE of
+//           its pairs (an entry with more pairs goes back on the stack) -- the 32-bucket L1 of the pair (the left histogram
+//           gathered from global memory, the right one read from the tile's copy in LDS, 8 v_sad_u8: 1 % of the pairs), then,
+//           for the 1e-5 that remain, the bit-parallel LCS of the pair on the SCALAR unit (raw_lcs_pair).  Entries carry
+//           their row and its length, so the stack outlives the length classes and is emptied once, at the end.
 //
 // Every test that drops a pair is an upper bound of the LCS: the hits are the one-stage kernel's, the exhaustive kernel's and
-// the oracle's.
+// the oracle's.  Where the time goes on configs[2] (200k x 200k, threshold 0.8, same box, variant builds NSM_C3C_X_*):
+// scan 3.11 ms (VALU-bound: 64 v_sad_u8 + 16 v_alignbit + one push per batch), pop / re-push 0.11, the 32-bucket test of
+// 4e8 pairs 0.39, 4.1e5 LCS 0.16 -- 3.76 ms against the one-stage kernel's 5.48 (two tiles per wave) and 6.54 (one).
 #pragma once
 
 namespace nsm {
@@ -26,14 +27,12 @@ namespace nsm {
 #ifndef NSM_C3C_TILES
 #define NSM_C3C_TILES 2
 #endif
-#ifndef NSM_C3C_RH
-#define NSM_C3C_RH 0
-#endif
 #ifndef NSM_C3C_ROWS
 #define NSM_C3C_ROWS 8
 #endif
 constexpr int kC3cStack = 192;  // entries per wave; drained when fewer than 64 slots are left
-// a stack entry: low word = the batch's pass mask (R rows x T tiles <= 32 bits), high word = first row << 6 | lane
+// a stack entry: low word = the batch's pass mask (R rows x T tiles <= 32 bits), high word = (first row - chunk start) << 13 |
+// la << 6 | lane  (a chunk has at most 2^15 rows: nsm_indel_raw_grid)
 
 // dynamic LDS: [wave][kC3cStack] u64 stack | [wave][T][8][64] u32 right histograms | [wave][T][64] u8 right lengths
 //              | lcsmin bytes
@@ -41,27 +40,27 @@ static inline size_t c3c_lds_bytes(int tiles) {
   return static_cast<size_t>(kWavesPerBlock) * (kC3cStack * 8 + static_cast<size_t>(tiles) * (8 * kWave * 4 + kWave)) + 136;
 }
 
-// LCS of ONE pair (left row `row`, right row `j` of `lb` code units; all three wave-uniform) on the SCALAR unit: lane k holds
-// code unit k of the left string, the right string arrives in 16 SGPRs, and per code unit c of it the match mask is a
-// ballot -- M = lanes whose code unit equals c -- so the recurrence V' = (V + (V & M)) | (V & ~M) runs on one 64-bit scalar:
-// one v_cmp and six SALU ops per code unit, no mask table, no LDS.  (The wave-wide form scores 64 texts against one pattern;
-// with one surviving pair per pattern -- 4e5 of them per configs[2] grid -- 63 of its 64 lanes computed nothing: 0.9 of
-// 4.2 ms.)  Left padding (code = alphabet) never equals a real code unit, and the loop stops at lb.
-__device__ __forceinline__ int raw_lcs_pair(const uint8_t* __restrict__ lcodes, int row, const uint8_t* __restrict__ rcodes, int j,
-                                            int lb, int lane) {
-  const uint32_t pat = lcodes[static_cast<size_t>(row) * 64 + lane];
-  const uint32_t* __restrict__ tw = reinterpret_cast<const uint32_t*>(rcodes + static_cast<size_t>(j) * 64);
-  uint32_t t[16];
-#pragma unroll
-  for (int q = 0; q < 16; ++q) t[q] = tw[q];
+// LCS of ONE pair (left row `row` of `la`, right row `j` of `lb` code units; all wave-uniform) on the SCALAR unit: lane k
+// holds code unit k of both strings (two 64-byte loads), v_readlane hands the right string's units to the scalar unit one
+// by one, and per unit c the match mask is a ballot -- M = lanes whose left unit equals c -- so the recurrence
+// V' = (V + (V & M)) | (V & ~M) runs on one 64-bit scalar: a v_readlane, a v_cmp and five SALU ops per code unit, no mask
+// table, no LDS, 50 VGPRs for the whole kernel.  (The wave-wide form scores 64 texts against one pattern; with one surviving
+// pair per pattern -- 4.1e5 of them per configs[2] grid -- 63 of its 64 lanes computed nothing: 0.9 of 4.2 ms, and its 32
+// address registers set the kernel's occupancy.)
+__device__ __forceinline__ int raw_lcs_pair(const uint8_t* __restrict__ lcodes, int row, int la, const uint8_t* __restrict__ rcodes,
+                                            int j, int lb, int lane) {
+  // lanes past the pattern hold a value no code unit equals, so the right string's padding (code = alphabet, like the left
+  // string's own) matches nothing and whole words can be processed without a per-unit length test
+  const uint32_t code = lcodes[static_cast<size_t>(row) * 64 + lane];
+  const uint32_t pat = lane < la ? code : 0x100u;
+  const uint32_t text = rcodes[static_cast<size_t>(j) * 64 + lane];
   unsigned long long v = ~0ull;
 #pragma unroll
   for (int w = 0; w < 16; ++w) {
-    if (4 * w >= lb) break;
+    if (4 * w < lb) {  // (wave-uniform; no `break`: the loop must unroll)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      if (4 * w + b < lb) {
-        const uint32_t c = (t[w] >> (8 * b)) & 0xffu;
+      for (int b = 0; b < 4; ++b) {
+        const uint32_t c = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(text), 4 * w + b));
         const unsigned long long m = __ballot(pat == c);
         const unsigned long long u = v & m;
         v = (v + u) | (v & ~m);
@@ -111,15 +110,9 @@ __global__ __launch_bounds__(kBlock) NSM_C3C_OCC void indel_raw_coarse_kernel(
     hc[t][0] = h.x; hc[t][1] = h.y; hc[t][2] = h.z; hc[t][3] = h.w;
     const uint4* fp = reinterpret_cast<const uint4*>(rhist + static_cast<size_t>(jc[t]) * 8);
     const uint4 f0 = fp[0], f1 = fp[1];
-#if NSM_C3C_RH == 1  // [t][lane][8]: one string's histogram contiguous, read back with two ds_read_b128
-    uint4* dst4 = reinterpret_cast<uint4*>(rh_lds + (t * kWave + lane) * 8);
-    dst4[0] = f0;
-    dst4[1] = f1;
-#else
     uint32_t* dst = rh_lds + t * 8 * kWave + lane;
     dst[0 * kWave] = f0.x; dst[1 * kWave] = f0.y; dst[2 * kWave] = f0.z; dst[3 * kWave] = f0.w;
     dst[4 * kWave] = f1.x; dst[5 * kWave] = f1.y; dst[6 * kWave] = f1.z; dst[7 * kWave] = f1.w;
-#endif
     rl_lds[t * kWave + lane] = static_cast<uint8_t>(lbj[t]);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -145,7 +138,8 @@ __global__ __launch_bounds__(kBlock) NSM_C3C_OCC void indel_raw_coarse_kernel(
     uint32_t bits = active ? static_cast<uint32_t>(e) : 0u;
     const uint32_t ehi = static_cast<uint32_t>(e >> 32);
     const int tl = static_cast<int>(ehi & 63u);
-    const int ib = static_cast<int>(ehi >> 6);
+    const int la = static_cast<int>((ehi >> 6) & 127u);
+    const int ib = i0 + static_cast<int>(ehi >> 13);
     const int pos = active ? 31 - __clz(bits) : 0;  // (an entry on the stack has a bit set)
     bits &= ~(1u << pos);
     const int k = R * T - 1 - pos;  // pair k of the batch: row k / T, tile k % T
@@ -153,34 +147,14 @@ __global__ __launch_bounds__(kBlock) NSM_C3C_OCC void indel_raw_coarse_kernel(
     const int row = active ? ib + r : i0;
     // the 32-bucket filter of the pair
     const uint4* lp = reinterpret_cast<const uint4*>(lhist + static_cast<size_t>(row) * 8);
-#ifdef NSM_C3C_X_NOLEFT  // (timing experiments: no gather of the left row)
-    const uint4 l0 = make_uint4(row, tl, 0, 0), l1v = make_uint4(0, 0, row, 1);
-    const int la = 40 + (row & 7);
-#else
     const uint4 l0 = lp[0], l1v = lp[1];
-    const int la = llen[row];
-#endif
     const int lb = rl_lds[t * kWave + tl];
     uint32_t rq[8];
-#if NSM_C3C_RH == 1
-    {
-      const uint4* rp4 = reinterpret_cast<const uint4*>(rh_lds + (t * kWave + tl) * 8);
-      const uint4 r0 = rp4[0], r1 = rp4[1];
-      rq[0] = r0.x; rq[1] = r0.y; rq[2] = r0.z; rq[3] = r0.w; rq[4] = r1.x; rq[5] = r1.y; rq[6] = r1.z; rq[7] = r1.w;
-    }
-#elif NSM_C3C_RH == 2  // (A/B builds: gathered from global memory)
-    {
-      const uint4* rp4 = reinterpret_cast<const uint4*>(rhist + static_cast<size_t>((tile0 + t) * kWave + tl) * 8);
-      const uint4 r0 = rp4[0], r1 = rp4[1];
-      rq[0] = r0.x; rq[1] = r0.y; rq[2] = r0.z; rq[3] = r0.w; rq[4] = r1.x; rq[5] = r1.y; rq[6] = r1.z; rq[7] = r1.w;
-    }
-#else
     {
       const uint32_t* rp = rh_lds + t * 8 * kWave + tl;
 #pragma unroll
       for (int q = 0; q < 8; ++q) rq[q] = rp[q * kWave];
     }
-#endif
     uint32_t l1 = 0;
     l1 = __builtin_amdgcn_sad_u8(l0.x, rq[0], l1);
     l1 = __builtin_amdgcn_sad_u8(l0.y, rq[1], l1);
@@ -205,6 +179,9 @@ __global__ __launch_bounds__(kBlock) NSM_C3C_OCC void indel_raw_coarse_kernel(
 #ifdef NSM_C3C_X_NOLCS  // (timing experiments)
     pass = false;
 #endif
+#ifdef NSM_C3C_X_FINEONLY  // (timing experiments: the 32-bucket test runs, nobody passes -- not known at compile time)
+    pass = pass && p.n_left < 0;
+#endif
     const int jp = (tile0 + t) * kWave + tl;
     for (unsigned long long todo = __ballot(pass); todo; todo &= todo - 1ull) {
       const int leader = __builtin_ctzll(todo);
@@ -212,8 +189,12 @@ __global__ __launch_bounds__(kBlock) NSM_C3C_OCC void indel_raw_coarse_kernel(
       const int j_s = __builtin_amdgcn_readlane(jp, leader);
       const int la_s = __builtin_amdgcn_readlane(la, leader);
       const int lb_s = __builtin_amdgcn_readlane(lb, leader);
-      const int lcs = raw_lcs_pair(lcodes, row_s, rcodes, j_s, lb_s, lane);
+      const int lcs = raw_lcs_pair(lcodes, row_s, la_s, rcodes, j_s, lb_s, lane);
+#ifdef NSM_C3C_X_COUNTLCS  // (experiments: one record per LCS call)
+      if (lane == 0)
+#else
       if (lcs >= need_of(la_s, lb_s) && lane == 0)
+#endif
         emit_hit(hits, p.cap, count, indel_score(la_s, lb_s, lcs), lorig[row_s], rorig[j_s]);
     }
   };
@@ -240,6 +221,7 @@ __global__ __launch_bounds__(kBlock) NSM_C3C_OCC void indel_raw_coarse_kernel(
     if (!__any(some)) continue;
 
     const uint32_t* __restrict__ hp = lh16 + static_cast<size_t>(a) * 4;
+    const uint32_t lane_field = (static_cast<uint32_t>(la) << 6) | static_cast<uint32_t>(lane);
     // the 4 R histogram dwords of a batch of `nrows` rows at hp_ (rows past the class re-read its last row; their bits are
     // dropped below)
     auto load_batch = [&](uint32_t (&h)[4 * R], const uint32_t* __restrict__ hp_, int nrows) {
@@ -278,7 +260,7 @@ __global__ __launch_bounds__(kBlock) NSM_C3C_OCC void indel_raw_coarse_kernel(
         if (m != 0ull) {  // one ds_write per batch: (first row, lane, mask)
           if (nz) {
             const int slot = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), static_cast<uint32_t>(q_cnt)));
-            stack[slot] = (static_cast<unsigned long long>((static_cast<uint32_t>(i) << 6) | static_cast<uint32_t>(lane)) << 32) | acc;
+            stack[slot] = (static_cast<unsigned long long>((static_cast<uint32_t>(i - i0) << 13) | lane_field) << 32) | acc;
           }
           q_cnt += __popcll(m);
         }
