@@ -562,10 +562,11 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
 #define NSM_TILE_PARK_MAX 24
 #endif
     q.park_max = NSM_TILE_PARK_MAX;
-    q.park_slots = kTileBatch * q.park_max;  // a row parks at most once, <= park_max pairs; drained after every batch
+    const int tile_rows = tile_batch(K);  // left rows per batch = mask tables per wave
+    q.park_slots = tile_rows * q.park_max;  // a row parks at most once, <= park_max pairs; drained after every batch
     const size_t tbl_bytes = (static_cast<size_t>(q.pm_stride) * tile_words(K) + kTileTableSkew) * 8;
-    const size_t wave_bytes = (kTileTables * tbl_bytes + kTileBatch * 3 * kTileHead * 4 + 2 * kTileBatch * kWave * K +
-                               kTileBatch * 2 * 4 + static_cast<size_t>(q.park_slots) * 12 + 15) & ~static_cast<size_t>(15);
+    const size_t wave_bytes = (tile_rows * tbl_bytes + tile_rows * 3 * kTileHead * 4 + 2 * tile_rows * kWave * K +
+                               tile_rows * 2 * 4 + static_cast<size_t>(q.park_slots) * 12 + 15) & ~static_cast<size_t>(15);
     auto block_bytes = [&](int n_img) -> size_t {
       const int n_hist = n_img > 3 ? n_img : 3;
       return static_cast<size_t>(n_img) * 16 * K * kWave * 4 + static_cast<size_t>(n_hist) * (8 * kWave * 4 + kWave * 4) +
@@ -605,7 +606,7 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
 #define NSM_TILE_ROUNDS 10
 #endif
     long long slices = (256ll * NSM_TILE_ROUNDS + n_tiles - 1) / n_tiles;
-    const long long max_slices = rows_cat / (static_cast<long long>(tw) * kTileBatch * 4) + 1;
+    const long long max_slices = rows_cat / (static_cast<long long>(tw) * tile_rows * 4) + 1;
     if (slices > max_slices) slices = max_slices;
     // ... and left slices that stay in an XCD's 4 MB L2 while its blocks (neighbouring tiles) walk them: <= 4096 rows
     // (heads, histograms and two level strings per row: ~0.2 KB + 2 x 64 K bytes)
@@ -616,7 +617,7 @@ extern "C" int nsm_indel_levels_grid(const nsm_level_items* left, const nsm_str_
     if (slices < 1) slices = 1;
     if (slices > 4096) slices = 4096;
     q.y_slices = static_cast<int>(slices);
-    q.rows_per_slice = static_cast<int>(((left->n + slices - 1) / slices + kTileBatch - 1) / kTileBatch * kTileBatch);
+    q.rows_per_slice = static_cast<int>(((left->n + slices - 1) / slices + tile_rows - 1) / tile_rows * tile_rows);
     const size_t lds_tile = block_bytes(n_img) + static_cast<size_t>(tw) * wave_bytes;
     const unsigned blocks = static_cast<unsigned>(8ll * ((n_tiles + 7) / 8) * slices);
 #define NSM_LAUNCH_TILE(KK)                                                                                        \

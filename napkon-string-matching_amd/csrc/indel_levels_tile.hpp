@@ -47,7 +47,7 @@ struct TileParams {
   int32_t use_h1;         // step-1 pre-filter: histogram bound of the step-1 pair itself (else lengths only)
   int32_t n_img;          // resident text images = steps whose right level string is in LDS (>= 2)
   int32_t park_max;       // park a row's survivors when at most this many of the 64 lanes are alive
-  int32_t park_slots;     // capacity of a wave's park: kTileBatch * park_max (a row parks at most once, <= park_max pairs)
+  int32_t park_slots;     // capacity of a wave's park: batch rows x park_max (a row parks at most once, <= park_max pairs)
   double threshold;
   unsigned long long cap;
 };
@@ -94,7 +94,9 @@ __global__ __launch_bounds__(tile_max_waves(K) * kWave) NSM_TILE_OCC void indel_
   constexpr int kRow = kWave * K;   // code units per string row
   constexpr int kDw = 16 * K;       // dwords per string row
   constexpr int NB = 8;             // histogram dwords per level string
-  constexpr int kBatch = kTileBatch;
+  constexpr int kBatch = tile_batch(K);
+  constexpr int kBatchLog = kBatch == 8 ? 3 : 2;
+  static_assert(kBatch == 4 || kBatch == 8, "4 or 8 left rows per batch");
   const int waves = blockDim.x >> 6;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
@@ -113,11 +115,11 @@ __global__ __launch_bounds__(tile_max_waves(K) * kWave) NSM_TILE_OCC void indel_
   // distance between a wave's tables: tbl_entries u64 plus a skew, so that the SAME symbol of different tables (the dense
   // pass reads one table per batch row) does not sit on the same LDS banks
   const int tbl_stride = tbl_entries + kTileTableSkew;
-  const size_t wave_bytes = static_cast<size_t>(kTileTables) * tbl_stride * 8 + kBatch * 3 * kTileHead * 4 +
+  const size_t wave_bytes = static_cast<size_t>(kBatch) * tbl_stride * 8 + kBatch * 3 * kTileHead * 4 +
                             2 * kBatch * kRow + kBatch * 2 * 4 + static_cast<size_t>(p.park_slots) * 12;
   unsigned char* wbase = wbase0 + wave * ((wave_bytes + 15) & ~static_cast<size_t>(15));
   unsigned long long* pm = reinterpret_cast<unsigned long long*>(wbase);
-  double* pk_score = reinterpret_cast<double*>(pm + static_cast<size_t>(kTileTables) * tbl_stride);
+  double* pk_score = reinterpret_cast<double*>(pm + static_cast<size_t>(kBatch) * tbl_stride);
   uint32_t* pk_meta = reinterpret_cast<uint32_t*>(pk_score + p.park_slots);
   uint32_t* head = pk_meta + p.park_slots;
   int32_t* srow = reinterpret_cast<int32_t*>(head + kBatch * 3 * kTileHead);
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(tile_max_waves(K) * kWave) NSM_TILE_OCC void indel_
         const uint32_t rows_here = wave_reduce_u32(fresh ? (1u << r) : 0u, [](uint32_t x, uint32_t y) { return x | y; });
         int la_max = 0;
 #pragma unroll
-        for (int q = 0; q < kTileBatch; ++q) {
+        for (int q = 0; q < kBatch; ++q) {
           if ((rows_here >> q) & 1u) {
             int lrow_q, la_q;
             left_level(q, s, lrow_q, la_q);
@@ -358,7 +360,8 @@ __global__ __launch_bounds__(tile_max_waves(K) * kWave) NSM_TILE_OCC void indel_
       const bool active = base + lane < pk_cnt;
       const int slot = active ? base + lane : base;
       const uint32_t meta = pk_meta[slot];
-      dense_steps(active, static_cast<int>(meta & 3u), static_cast<int>((meta >> 2) & 63u), static_cast<int>(meta >> 8),
+      dense_steps(active, static_cast<int>(meta & (kBatch - 1)), static_cast<int>((meta >> kBatchLog) & 63u),
+                  static_cast<int>(meta >> (kBatchLog + 6)),
                   pk_score[slot], true);
     }
     pk_cnt = 0;
@@ -382,13 +385,14 @@ __global__ __launch_bounds__(tile_max_waves(K) * kWave) NSM_TILE_OCC void indel_
     if (who == 0ull) return false;
     const int n = __popcll(who);
     // many survivors go on wave-wide (the scan picks the text source: resident image, or global memory for deep items);
-    // few are parked: a row parks at most once, so kTileBatch * park_max slots always suffice
+    // few are parked: a row parks at most once, so batch rows x park_max slots always suffice
     if (n > p.park_max) return true;
     if (alive) {
       const int slot = pk_cnt + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(who >> 32),
                                                           __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(who), 0u));
       pk_score[slot] = score;
-      pk_meta[slot] = static_cast<uint32_t>(r) | (static_cast<uint32_t>(lane) << 2) | (static_cast<uint32_t>(s + 1) << 8);
+      pk_meta[slot] = static_cast<uint32_t>(r) | (static_cast<uint32_t>(lane) << kBatchLog) |
+                      (static_cast<uint32_t>(s + 1) << (kBatchLog + 6));
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -425,7 +429,7 @@ __global__ __launch_bounds__(tile_max_waves(K) * kWave) NSM_TILE_OCC void indel_
         v[g] = reinterpret_cast<const uint32_t*>(lcodes + static_cast<size_t>(lrow) * kRow)[d];
       }
       if (lane < 3 * kBatch) {
-        const int r = lane & (kBatch - 1), t = lane >> 2;  // (kBatch == 4)
+        const int r = lane & (kBatch - 1), t = lane >> kBatchLog;
         const int hl = srow[2 * r], hf = srow[2 * r + 1];
         const int lrow = hf + max(0, min(t + 1, hl - 1));
         uint32_t h[NB];

@@ -5,8 +5,15 @@
 
 namespace nsm {
 
-constexpr int kTileBatch = 4;   // left rows staged together
-constexpr int kTileTables = 4;  // mask tables per wave: the scan uses two (two rows per pass), the dense pass one per batch row
+// left rows staged together = mask tables per wave (the scan uses two -- two rows per pass --, the dense pass one per batch
+// row).  The lane-per-pair dense passes pool the parked pairs of ONE batch and run at 16..20 of 64 lanes; for one-word
+// strings a table is only 0.6 KB, so 8 rows per batch fit (NSM_TILE_BATCH_K1=8) -- measured on 3 x 100k^2 word-like grids
+// at 0.5 / 0.45: 37.8 / 58.4 ms against 38.6 / 58.6 with 4 (the passes halve, the mask tables to build per row do not, and
+// the staging registers spill): kept at 4.
+#ifndef NSM_TILE_BATCH_K1
+#define NSM_TILE_BATCH_K1 4
+#endif
+constexpr int tile_batch(int K) { return K == 1 ? NSM_TILE_BATCH_K1 : 4; }
 constexpr int kTileHead = 12;   // dwords per head: histogram (8) | la | level row | levels | first row
 #ifndef NSM_TILE_TBL_SKEW
 #define NSM_TILE_TBL_SKEW 0
