@@ -83,6 +83,8 @@ def parse_args():
     ap.add_argument("--threshold", type=float, default=None, help="override the workload's threshold (debug)")
     ap.add_argument("--id-range", type=int, default=0, help="c2 / c4: draw token ids from [0, N) instead of 2^17 (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--postings64", action="store_true",
+                    help="64-bit posting entries even where the 32-bit ones fit (A/B runs of the global-index kernels)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the exhaustive (prune off) run and c5w's second run at the score threshold (profiling passes)")
     ap.add_argument("--graph", type=int, default=0, help="1: replay each step as one captured hipGraph")
@@ -160,7 +162,7 @@ class Workload:
             self.launch_fn = self.lib.nsm_jaccard_raw_grid
             # the right table carries a global inverted index (tables.SetTable.from_padded): on these vocabularies the
             # library generates candidates from it at every threshold (csrc/jaccard_raw_global.hip)
-            self.kernel = self.kernel_match = "jaccard_raw_global_kernel<16>"
+            self.kernel = self.kernel_match = "jaccard_raw_global_kernel<16"  # (<16, true>: 32-bit posting entries)
             self.kernel_match_exhaustive = "jaccard_raw_kernel<16, false>"
             self.dtype = "int32"
             self.label = (f"{name.upper()}: {n}x{m} token-id sets/GPU (Poisson(8) ids, W=16), intersection_vs_union RAW, "
@@ -443,7 +445,7 @@ def valu_roofline(profile_name, kernel_match, kernel_label, kernel_ms, launches_
 def global_index_bytes(work):
     """Algorithmic bytes of one launch of jaccard_raw_global_kernel on this workload: what the prefix-filter probe has to
     touch whatever the implementation -- every left row (64 B of ids + its size), two offsets per probed id, every posting
-    entry of the probed lists' useful classes (8 B each), and the signature words of the candidates the entry-only tests
+    entry of the probed lists' useful classes (4 B each, 8 B when the table has too many rows for the compact entry), and the signature words of the candidates the entry-only tests
     keep (not counted: data dependent, a few per cent of the entries).  Prefix lengths and posting classes as
     csrc/jaccard_raw_global.hip computes them (the same double arithmetic for kmin)."""
     import numpy as np
@@ -468,8 +470,9 @@ def global_index_bytes(work):
     toks = toks[toks < work.right.vocab]
     ps = work.right.post_start.cpu().numpy().astype(np.int64)
     visited = int((ps[5 * toks + cls_end] - ps[5 * toks]).sum())
-    return {"posting_entries_visited": visited, "probes": int(probe.sum()),
-            "bytes": visited * 8 + ids.shape[0] * (ids.shape[1] * 4 + 4) + int(probe.sum()) * 8}
+    entry_bytes = 4 if work.right.post_row_bits else 8  # (32-bit posting entries when the rows fit: nsm_hip.h, post)
+    return {"posting_entries_visited": visited, "probes": int(probe.sum()), "posting_entry_bytes": entry_bytes,
+            "bytes": visited * entry_bytes + ids.shape[0] * (ids.shape[1] * 4 + 4) + int(probe.sum()) * 8}
 
 
 def hbm_roofline(profile_name, kernel_match, kernel_label, kernel_ms, algorithmic, n_hits, default_shape=True):
@@ -1042,6 +1045,11 @@ def run_raw(args, comm, device, name, rows=0, right_rows=0, threshold=None, step
 def main():
     args = parse_args()
     import torch
+
+    if args.postings64:
+        from napkon_string_matching_amd import tables as _tables
+
+        _tables.COMPACT_POSTINGS = False
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -12,6 +12,7 @@
 // lane 0 of a wavefront as its largest row and were silently wrong otherwise).  They synchronise `stream`
 // before they return: the row count of a partitioned table and the validation verdict live on the device.
 #include <cstring>
+#include <type_traits>
 
 #include <rocprim/rocprim.hpp>
 
@@ -289,14 +290,18 @@ __global__ void set_gather_kernel(const int32_t* __restrict__ perm, const int32_
 // (unused slots: all ones, sorted last), one radix sort, then the offsets: 5 boundaries per id (positions < 1, 2, 4, 8, any).
 __device__ __forceinline__ int post_class(int pos) { return pos < 1 ? 0 : pos < 2 ? 1 : pos < 4 ? 2 : pos < 8 ? 3 : 4; }
 
+// VAL = unsigned long long: entry = row | position << 32 | cnt << 40; VAL = uint32_t (row_bits > 0): the compact entry
+// row | position << row_bits | (cnt - 1) << (row_bits + log2 width)
+template <typename VAL>
 __global__ void post_keys_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ cnt, const int32_t* __restrict__ seg,
-                                 int rows, int width, int vocab, unsigned long long* __restrict__ keys,
-                                 unsigned long long* __restrict__ vals, Status* st) {
+                                 int rows, int width, int vocab, int row_bits, int width_log, unsigned long long* __restrict__ keys,
+                                 VAL* __restrict__ vals, Status* st) {
   const long long s = static_cast<long long>(blockIdx.x) * kThreads + threadIdx.x;
   if (s >= static_cast<long long>(rows) * width) return;
   const int r = static_cast<int>(s / width), k = static_cast<int>(s % width);
   const int c = cnt[r];
-  unsigned long long key = ~0ull, val = 0ull;
+  unsigned long long key = ~0ull;
+  VAL val = 0;
   if (k < c) {
     const int32_t id = ids[s];
     if (id >= vocab) atomicMax(&st->err, static_cast<int>(kErrBadVocab));
@@ -305,8 +310,11 @@ __global__ void post_keys_kernel(const int32_t* __restrict__ ids, const int32_t*
       const unsigned long long tok = (seg ? static_cast<unsigned long long>(seg[r]) * static_cast<unsigned long long>(vocab) : 0ull) +
                                      static_cast<unsigned long long>(static_cast<uint32_t>(id));
       key = (tok << 8) | static_cast<unsigned long long>(k);
-      val = static_cast<unsigned long long>(static_cast<uint32_t>(r)) | (static_cast<unsigned long long>(k) << 32) |
-            (static_cast<unsigned long long>(c) << 40);
+      if constexpr (sizeof(VAL) == 8)
+        val = static_cast<unsigned long long>(static_cast<uint32_t>(r)) | (static_cast<unsigned long long>(k) << 32) |
+              (static_cast<unsigned long long>(c) << 40);
+      else
+        val = static_cast<uint32_t>(r) | (static_cast<uint32_t>(k) << row_bits) | (static_cast<uint32_t>(c - 1) << (row_bits + width_log));
     }
   }
   keys[s] = key;
@@ -317,8 +325,9 @@ __global__ void post_keys_kernel(const int32_t* __restrict__ ids, const int32_t*
 // entries whose class key is below q.  The last entry e of every run of equal class keys k writes e + 1 to slot k + 1 of the
 // zeroed array; a forward MAX-scan then fills the slots of the empty (id, class) lists -- most of the key space of a
 // partitioned levels table, where one thread walking a gap took 41 ms per table (profiles/pmc_c5.json of round 4).
+template <typename VAL>
 __global__ void post_bounds_kernel(const unsigned long long* __restrict__ keys, long long n, int vocab, unsigned long long key_mask,
-                                   int32_t* __restrict__ post_start, unsigned long long* __restrict__ vals) {
+                                   int32_t* __restrict__ post_start, VAL* __restrict__ vals) {
   const long long e = static_cast<long long>(blockIdx.x) * kThreads + threadIdx.x;
   if (e >= n) return;
   const long long sentinel = 5ll * vocab;
@@ -330,7 +339,7 @@ __global__ void post_bounds_kernel(const unsigned long long* __restrict__ keys, 
   };
   const long long cur = ckey(e);
   if (cur == sentinel) {
-    vals[e] = 0ull;  // (the tail stays zero whatever the sort left there)
+    vals[e] = 0;  // (the tail stays zero whatever the sort left there)
     return;
   }
   if (ckey(e + 1) != cur) post_start[cur + 1] = static_cast<int32_t>(e + 1);
@@ -608,9 +617,15 @@ extern "C" int nsm_build_set_table(const int32_t* ids_in, int32_t n, int32_t wid
       return NSM_E_BADARG;
     }
     const long long slots = static_cast<long long>(rows) * width;
+    const int row_bits = out->post_row_bits;
+    int width_log = 0;
+    while ((1 << width_log) < width) ++width_log;
+    if (row_bits < 0 || (row_bits > 0 && (row_bits + 2 * width_log > 32 || (static_cast<long long>(rows) > (1ll << row_bits))))) {
+      set_error("%s: post_row_bits %d cannot hold %d rows of width %d in a 32-bit posting entry", who, row_bits, rows, width);
+      return NSM_E_BADARG;
+    }
     unsigned long long* keys = sc.get<unsigned long long>(slots);
     unsigned long long* keys_sorted = sc.get<unsigned long long>(slots);
-    unsigned long long* vals = sc.get<unsigned long long>(slots);
     d_sq = sc.get<unsigned long long>(5);
     if (sc.failed) return hip_status(hipErrorOutOfMemory, "builder scratch");
     (void)hipMemsetAsync(d_sq, 0, 5 * sizeof(unsigned long long), stream);
@@ -618,10 +633,18 @@ extern "C" int nsm_build_set_table(const int32_t* ids_in, int32_t n, int32_t wid
     while ((1ll << bits) < n_keys) ++bits;
     bits += 8;
     const unsigned long long key_mask = (1ull << bits) - 1ull;
-    unsigned long long* post = const_cast<unsigned long long*>(reinterpret_cast<const unsigned long long*>(out->post));
-    if (slots > 0) {
-      hipLaunchKernelGGL(post_keys_kernel, blocks_for(slots), dim3(kThreads), 0, stream, out->ids, out->cnt,
-                         partition ? out->seg : static_cast<const int32_t*>(nullptr), rows, width, out->vocab, keys, vals, d_status);
+    int32_t* post_start = const_cast<int32_t*>(out->post_start);
+    const size_t n_bounds = static_cast<size_t>(5 * n_keys + 1);
+    (void)hipMemsetAsync(post_start, 0, n_bounds * sizeof(int32_t), stream);
+    // (the entry type only changes the sort's value type and two stores)
+    auto fill = [&](auto* post) -> int {
+      using VAL = std::remove_pointer_t<decltype(post)>;
+      if (slots <= 0) return 0;
+      VAL* vals = sc.get<VAL>(slots);
+      if (sc.failed) return hip_status(hipErrorOutOfMemory, "builder scratch");
+      hipLaunchKernelGGL(post_keys_kernel<VAL>, blocks_for(slots), dim3(kThreads), 0, stream, out->ids, out->cnt,
+                         partition ? out->seg : static_cast<const int32_t*>(nullptr), rows, width, out->vocab, row_bits, width_log,
+                         keys, vals, d_status);
       size_t bytes = 0;
       hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, keys, keys_sorted, vals, post, static_cast<size_t>(slots), 0u,
                                                static_cast<unsigned>(bits), stream);
@@ -631,13 +654,12 @@ extern "C" int nsm_build_set_table(const int32_t* ids_in, int32_t n, int32_t wid
       e = rocprim::radix_sort_pairs(temp, bytes, keys, keys_sorted, vals, post, static_cast<size_t>(slots), 0u,
                                     static_cast<unsigned>(bits), stream);
       if (e != hipSuccess) return hip_status(e, "radix_sort_pairs (postings)");
-    }
-    int32_t* post_start = const_cast<int32_t*>(out->post_start);
-    const size_t n_bounds = static_cast<size_t>(5 * n_keys + 1);
-    (void)hipMemsetAsync(post_start, 0, n_bounds * sizeof(int32_t), stream);
-    if (slots > 0)
-      hipLaunchKernelGGL(post_bounds_kernel, blocks_for(slots), dim3(kThreads), 0, stream, keys_sorted, slots,
+      hipLaunchKernelGGL(post_bounds_kernel<VAL>, blocks_for(slots), dim3(kThreads), 0, stream, keys_sorted, slots,
                          static_cast<int>(n_keys), key_mask, post_start, post);
+      return 0;
+    };
+    void* post_col = const_cast<void*>(static_cast<const void*>(out->post));
+    if (int rc = row_bits > 0 ? fill(static_cast<uint32_t*>(post_col)) : fill(static_cast<unsigned long long*>(post_col))) return rc;
     {
       size_t bytes = 0;
       hipError_t e = rocprim::inclusive_scan(nullptr, bytes, post_start, post_start, n_bounds, rocprim::maximum<int32_t>(), stream);

@@ -31,11 +31,13 @@ struct JacLevGlobalParams {
   int32_t lev_stride_l;
   int32_t lev_stride_r;
   int32_t cat_mode;
+  int32_t row_bits;  // 0: 64-bit posting entries; else 32-bit entries with this many row bits (nsm_hip.h: post)
   double threshold;
   unsigned long long cap;
 };
 
-template <int W>
+// COMPACT: the right table's posting entries are 32 bits (the row in the low row_bits)
+template <int W, bool COMPACT>
 __global__ __launch_bounds__(kBlock) void jaccard_levels_global_kernel(
     const int32_t* __restrict__ lids, const int32_t* __restrict__ lcnt, const uint8_t* __restrict__ lplen,
     const uint32_t* __restrict__ lfilt, const int32_t* __restrict__ lorig, const int32_t* __restrict__ lseg,
@@ -107,9 +109,16 @@ __global__ __launch_bounds__(kBlock) void jaccard_levels_global_kernel(
         const int mid = seg + step;
         if (s_off[wave][mid] <= idx) seg = mid;
       }
-      unsigned long long entry = 0ull;
-      if (live) entry = post[static_cast<size_t>(s_start[wave][seg]) + (idx - s_off[wave][seg])];
-      const int rrow = static_cast<int>(static_cast<uint32_t>(entry));
+      int rrow = 0;  // the posting entry's right row (position and size are not used here)
+      if constexpr (COMPACT) {
+        uint32_t e = 0u;
+        if (live) e = reinterpret_cast<const uint32_t*>(post)[static_cast<size_t>(s_start[wave][seg]) + (idx - s_off[wave][seg])];
+        rrow = static_cast<int>(e & ((1u << p.row_bits) - 1u));
+      } else {
+        unsigned long long entry = 0ull;
+        if (live) entry = post[static_cast<size_t>(s_start[wave][seg]) + (idx - s_off[wave][seg])];
+        rrow = static_cast<int>(static_cast<uint32_t>(entry));
+      }
       const int lsub = seg >> kSlotShift, pa = seg & (W - 1);
       const uint32_t* lf = s_lf[wave][lsub];
       // ---- filter on the two 32-byte records
@@ -218,13 +227,19 @@ int launch_levels_global(const nsm_set_table* l, const nsm_set_table* r, double 
   p.n_left = l->n; p.n_right = r->n; p.vocab = r->vocab; p.partitioned = l->seg != nullptr ? 1 : 0;
   p.lev_stride_l = l->max_levels; p.lev_stride_r = r->max_levels; p.cat_mode = category_mode;
   p.threshold = threshold; p.cap = capacity;
+  p.row_bits = r->post_row_bits;
   constexpr int kRows = kWave / W;
   p.n_batches = (l->n + kRows - 1) / kRows;
   long long blocks = (p.n_batches + kWavesPerBlock - 1) / kWavesPerBlock;
   if (blocks > 256 * 8) blocks = 256 * 8;
-  hipLaunchKernelGGL((jaccard_levels_global_kernel<W>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, l->ids, l->cnt,
-                     l->plen, l->filt, l->orig, l->seg, r->ids, r->plen, r->filt, r->orig,
-                     reinterpret_cast<const unsigned long long*>(r->post), r->post_start, hits, hit_count, p);
+  if (p.row_bits > 0)
+    hipLaunchKernelGGL((jaccard_levels_global_kernel<W, true>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, l->ids,
+                       l->cnt, l->plen, l->filt, l->orig, l->seg, r->ids, r->plen, r->filt, r->orig,
+                       reinterpret_cast<const unsigned long long*>(r->post), r->post_start, hits, hit_count, p);
+  else
+    hipLaunchKernelGGL((jaccard_levels_global_kernel<W, false>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, l->ids,
+                       l->cnt, l->plen, l->filt, l->orig, l->seg, r->ids, r->plen, r->filt, r->orig,
+                       reinterpret_cast<const unsigned long long*>(r->post), r->post_start, hits, hit_count, p);
   return hip_status(hipGetLastError(), "jaccard_levels_global_kernel launch");
 }
 

@@ -32,12 +32,14 @@ struct JacGlobalParams {
   int32_t rows_per_batch;  // 64 >> slot_shift
   int32_t n_batches;
   int32_t cls_end;         // which of a list's five boundaries ends the useful entries (1..5)
+  int32_t row_bits;        // 0: 64-bit posting entries; else 32-bit entries with this many row bits (nsm_hip.h: post)
   unsigned long long cap;
   uint8_t kmin[2 * W + 4];  // indexed by |A| + |B|
   uint8_t prefix[W + 4];    // P(size)
 };
 
-template <int W>
+// COMPACT: the right table's posting entries are 32 bits (row | position << row_bits | (size - 1) << (row_bits + log2 W))
+template <int W, bool COMPACT>
 __global__ __launch_bounds__(kBlock) void jaccard_raw_global_kernel(
     const int32_t* __restrict__ lids, const int32_t* __restrict__ lcnt, const uint64_t* __restrict__ lsig,
     const uint64_t* __restrict__ lsig2, const int32_t* __restrict__ lorig, const int32_t* __restrict__ rids,
@@ -112,11 +114,22 @@ __global__ __launch_bounds__(kBlock) void jaccard_raw_global_kernel(
         const int mid = seg + step;
         if (s_off[wave][mid] <= idx) seg = mid;
       }
-      unsigned long long entry = 0ull;
-      if (live) entry = post[static_cast<size_t>(s_start[wave][seg]) + (idx - s_off[wave][seg])];
-      const int rrow = static_cast<int>(static_cast<uint32_t>(entry));
-      const int pb = static_cast<int>((entry >> 32) & 0xffu);
-      const int b = static_cast<int>((entry >> 40) & 0xffu);
+      // the posting entry: right row, position of the probed id in it, its size
+      int rrow, pb, b;
+      if constexpr (COMPACT) {
+        constexpr int kLogW = W == 16 ? 4 : W == 32 ? 5 : 6;
+        uint32_t e = 0u;
+        if (live) e = reinterpret_cast<const uint32_t*>(post)[static_cast<size_t>(s_start[wave][seg]) + (idx - s_off[wave][seg])];
+        rrow = static_cast<int>(e & ((1u << p.row_bits) - 1u));
+        pb = static_cast<int>((e >> p.row_bits) & (W - 1));
+        b = live ? static_cast<int>((e >> (p.row_bits + kLogW)) & (W - 1)) + 1 : 0;
+      } else {
+        unsigned long long entry = 0ull;
+        if (live) entry = post[static_cast<size_t>(s_start[wave][seg]) + (idx - s_off[wave][seg])];
+        rrow = static_cast<int>(static_cast<uint32_t>(entry));
+        pb = static_cast<int>((entry >> 32) & 0xffu);
+        b = static_cast<int>((entry >> 40) & 0xffu);
+      }
       const int meta = s_meta[wave][seg];
       const int pa = meta & 0xff, la = meta >> 8;
       const int need = s_kmin[la + b];
@@ -193,6 +206,7 @@ int launch_raw_global(const nsm_set_table* l, const nsm_set_table* r, double thr
                       unsigned long long* hit_count, hipStream_t stream, bool probe_only, double* estimate) {
   JacGlobalParams<W> p;
   p.n_left = l->n; p.n_right = r->n; p.vocab = r->vocab; p.cap = capacity;
+  p.row_bits = r->post_row_bits;
   fill_kmin<W>(p.kmin, threshold);
   for (int s = 0; s < 2 * W + 4; ++s)
     if (p.kmin[s] == 0) {  // a threshold <= 0: every pair hits, no index can help
@@ -220,9 +234,14 @@ int launch_raw_global(const nsm_set_table* l, const nsm_set_table* r, double thr
   if (probe_only || longest == 0) return 0;  // (longest == 0: no pair of sizes can reach the threshold)
   long long blocks = (p.n_batches + kWavesPerBlock - 1) / kWavesPerBlock;
   if (blocks > 256 * 8) blocks = 256 * 8;
-  hipLaunchKernelGGL((jaccard_raw_global_kernel<W>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, l->ids, l->cnt,
-                     l->sig, (l->sig2 && r->sig2) ? l->sig2 : nullptr, l->orig, r->ids, r->sig, r->sig2, r->orig,
-                     reinterpret_cast<const unsigned long long*>(r->post), r->post_start, hits, hit_count, p);
+  if (p.row_bits > 0)
+    hipLaunchKernelGGL((jaccard_raw_global_kernel<W, true>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, l->ids,
+                       l->cnt, l->sig, (l->sig2 && r->sig2) ? l->sig2 : nullptr, l->orig, r->ids, r->sig, r->sig2, r->orig,
+                       reinterpret_cast<const unsigned long long*>(r->post), r->post_start, hits, hit_count, p);
+  else
+    hipLaunchKernelGGL((jaccard_raw_global_kernel<W, false>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, l->ids,
+                       l->cnt, l->sig, (l->sig2 && r->sig2) ? l->sig2 : nullptr, l->orig, r->ids, r->sig, r->sig2, r->orig,
+                       reinterpret_cast<const unsigned long long*>(r->post), r->post_start, hits, hit_count, p);
   return hip_status(hipGetLastError(), "jaccard_raw_global_kernel launch");
 }
 

@@ -47,6 +47,7 @@ class NsmSetTable(ctypes.Structure):
         ("post", ctypes.c_void_p),
         ("post_start", ctypes.c_void_p),
         ("post_sq", ctypes.c_uint64 * 5),
+        ("post_row_bits", ctypes.c_int32),
     ]
 
 

@@ -52,10 +52,20 @@ def _id_limit(orig, n: int) -> int:
     return 0 if int(o.min()) < 0 else int(o.max()) + 1
 
 
-def inverted_index(ids: np.ndarray, cnt: np.ndarray, vocab: int, seg: Optional[np.ndarray] = None):
+COMPACT_POSTINGS = True  # (tests switch it off to cover the 64-bit entries at small sizes)
+
+
+def post_row_bits(rows: int, width: int) -> int:
+    """Row bits of the 32-bit posting entry (row | position << bits | (cnt - 1) << (bits + log2 width)), 0 when the
+    table's rows do not fit beside the two width-sized fields: 64-bit entries then (include/nsm_hip.h: post)."""
+    bits = 32 - 2 * (int(width).bit_length() - 1)
+    return bits if (COMPACT_POSTINGS and rows <= (1 << bits)) else 0
+
+
+def inverted_index(ids: np.ndarray, cnt: np.ndarray, vocab: int, seg: Optional[np.ndarray] = None, row_bits: int = 0):
     """The global inverted index of a set table (include/nsm_hip.h: post / post_start / post_sq), the numpy way --
     what ``nsm_build_set_table`` builds on the GPU, byte for byte.  ``ids`` [n][W] (RAW: ascending per row), ``cnt`` [n];
-    ``seg`` [n]: a partitioned levels table keys its postings by (category segment, id)."""
+    ``seg`` [n]: a partitioned levels table keys its postings by (category segment, id); ``row_bits`` > 0: 32-bit entries."""
     n, width = ids.shape
     valid = np.arange(width, dtype=np.int64)[None, :] < np.asarray(cnt, dtype=np.int64)[:, None]
     r_idx, k_idx = np.nonzero(valid)  # row-major: the stable sort below keeps rows ascending inside one (id, position)
@@ -66,9 +76,15 @@ def inverted_index(ids: np.ndarray, cnt: np.ndarray, vocab: int, seg: Optional[n
         tok = np.asarray(seg, dtype=np.int64)[r_idx] * vocab + tok
         vocab = 64 * vocab
     order = np.lexsort((k_idx, tok))
-    entry = (r_idx.astype(np.uint64) | (k_idx.astype(np.uint64) << np.uint64(32)) |
-             (np.asarray(cnt, dtype=np.uint64)[r_idx] << np.uint64(40)))
-    post = np.zeros(n * width, dtype=np.uint64)
+    if row_bits > 0:
+        wl = int(width).bit_length() - 1
+        entry = (r_idx.astype(np.uint32) | (k_idx.astype(np.uint32) << np.uint32(row_bits)) |
+                 ((np.asarray(cnt, dtype=np.uint32)[r_idx] - np.uint32(1)) << np.uint32(row_bits + wl)))
+        post = np.zeros(n * width, dtype=np.uint32)
+    else:
+        entry = (r_idx.astype(np.uint64) | (k_idx.astype(np.uint64) << np.uint64(32)) |
+                 (np.asarray(cnt, dtype=np.uint64)[r_idx] << np.uint64(40)))
+        post = np.zeros(n * width, dtype=np.uint64)
     post[: len(order)] = entry[order]
     k_s = k_idx[order]
     cls = np.where(k_s < 1, 0, np.where(k_s < 2, 1, np.where(k_s < 4, 2, np.where(k_s < 8, 3, 4))))
@@ -236,6 +252,7 @@ class SetTable:
     post_start: Optional[torch.Tensor] = None
     vocab: int = 0
     post_sq: Tuple[int, ...] = (0, 0, 0, 0, 0)
+    post_row_bits: int = 0  # > 0: ``post`` holds 32-bit entries with this many row bits (``post_row_bits(rows, width)``)
     id_limit: int = 0  # every ``orig`` entry is below it (the sort's key width, nsm_sort_hits); 0 = unknown
 
     # ------------------------------------------------------------------ builders
@@ -481,10 +498,12 @@ class SetTable:
             filt[:, 6] = (sig_l1 >> np.uint64(32)).astype(np.uint32)
         post = post_start = None
         post_sq = (0, 0, 0, 0, 0)
+        row_bits = post_row_bits(n, width) if index_vocab else 0
         if index_vocab:
-            post, post_start, post_sq = inverted_index(ids, cnt_s, index_vocab, seg=seg)
+            post, post_start, post_sq = inverted_index(ids, cnt_s, index_vocab, seg=seg, row_bits=row_bits)
         return cls(
-            post=None if post is None else _dev(post.view(np.int64), device),
+            post=None if post is None else _dev(post.view(np.int32 if row_bits else np.int64), device),
+            post_row_bits=row_bits,
             post_start=None if post_start is None else _dev(post_start, device), vocab=int(index_vocab), post_sq=post_sq,
             filt=None if filt is None else _dev(filt, device),
             ids=_dev(ids, device),
@@ -543,7 +562,8 @@ class SetTable:
             filt=new((cap, 8), torch.int32) if levels else None,
             max_levels=max_levels, seg=new(cap, torch.int32) if do_part else None,
             seg_start=new(65, torch.int32) if do_part else None, category_mode=out_mode if levels else None,
-            post=new(cap * width, torch.int64) if index_vocab else None,
+            post=new(cap * width, torch.int32 if post_row_bits(rows, width) else torch.int64) if index_vocab else None,
+            post_row_bits=post_row_bits(rows, width) if index_vocab else 0,
             post_start=new(5 * index_vocab * (64 if do_part else 1) + 1, torch.int32) if index_vocab else None,
             vocab=int(index_vocab),
         )
@@ -575,7 +595,7 @@ class SetTable:
             ptr(self.nlev),
             ptr(self.plen),
             ptr(self.cat), ptr(self.filt), ptr(self.seg), ptr(self.seg_start), self.n, self.width, self.max_levels,
-            self.vocab, ptr(self.post), ptr(self.post_start), (ctypes.c_uint64 * 5)(*self.post_sq),
+            self.vocab, ptr(self.post), ptr(self.post_start), (ctypes.c_uint64 * 5)(*self.post_sq), self.post_row_bits,
         )
 
     def nbytes(self) -> int:

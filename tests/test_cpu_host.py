@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.nsm_abi_version() == _lib.ABI_VERSION
     # struct layouts must match the header (sizes on LP64)
     assert ctypes.sizeof(_lib.NsmHit) == 16
-    assert ctypes.sizeof(_lib.NsmSetTable) == 12 * 8 + 4 * 4 + 2 * 8 + 5 * 8
+    assert ctypes.sizeof(_lib.NsmSetTable) == 12 * 8 + 4 * 4 + 2 * 8 + 5 * 8 + 8  # (ABI 5: post_row_bits + padding)
     assert ctypes.sizeof(_lib.NsmStrTable) == 5 * 8 + 3 * 4 + 4 + 8  # (ABI 5: hist16)
     assert ctypes.sizeof(_lib.NsmLevelItems) == 6 * 8 + 4 + 4
 
@@ -83,6 +83,8 @@ def test_product_never_imports_oracle():
 
 
 def test_set_table_encoding_cpu():
+    import torch
+
     from napkon_string_matching_amd import tables
 
     ids = np.array([[5, -1, 9, 2], [-1, -1, -1, -1], [7, 8, -1, -1]], dtype=np.int32)
@@ -95,8 +97,20 @@ def test_set_table_encoding_cpu():
     assert row0[:3] == [2, 5, 9] and set(row0[3:]) == {-2}  # RAW rows: ids ascending (the inverted index's global order)
     # right tables carry the global inverted index: one entry per (row, id) sorted by (id, position), 5 offsets per id
     assert t.vocab == 10 and t.post_start.shape[0] == 51 and t.post_sq == (2, 4, 5, 5, 5)
-    entries = [(int(e) & 0xFFFFFFFF, (int(e) >> 32) & 0xFF, (int(e) >> 40) & 0xFF) for e in t.post[:5].numpy().view(np.uint64)]
-    assert entries == [(0, 0, 3), (0, 1, 3), (1, 0, 2), (1, 1, 2), (0, 2, 3)]  # ids 2, 5, 7, 8, 9 -> (row, position, size)
+    # 3 rows of width 16: 32-bit entries, row | position << 24 | (size - 1) << 28
+    assert t.post_row_bits == 24 and t.post.dtype == torch.int32
+    entries = [(int(e) & 0xFFFFFF, (int(e) >> 24) & 0xF, ((int(e) >> 28) & 0xF) + 1) for e in t.post[:5].numpy().view(np.uint32)]
+    want = [(0, 0, 3), (0, 1, 3), (1, 0, 2), (1, 1, 2), (0, 2, 3)]  # ids 2, 5, 7, 8, 9 -> (row, position, size)
+    assert entries == want
+    tables.COMPACT_POSTINGS = False  # the 64-bit entries of tables with too many rows: row | position << 32 | size << 40
+    try:
+        t64 = tables.SetTable.from_padded(ids, "right", "cpu")
+    finally:
+        tables.COMPACT_POSTINGS = True
+    assert t64.post_row_bits == 0 and t64.post.dtype == torch.int64
+    assert [(int(e) & 0xFFFFFFFF, (int(e) >> 32) & 0xFF, (int(e) >> 40) & 0xFF) for e in t64.post[:5].numpy().view(np.uint64)] == want
+    assert t64.post_start.tolist() == t.post_start.tolist() and t64.post_sq == t.post_sq
+    assert tables.post_row_bits(1 << 24, 16) == 24 and tables.post_row_bits((1 << 24) + 1, 16) == 0 and tables.post_row_bits(1 << 20, 64) == 20
     assert t.post_start[5 * 2: 5 * 2 + 6].tolist() == [0, 1, 1, 1, 1, 1] and int(t.post_start[-1]) == 5
     assert tables.SetTable.from_padded(ids, "left", "cpu").post is None
     assert tables.SetTable.from_padded(ids, "left", "cpu").ids[2].tolist() == [-1] * 16

@@ -31,7 +31,7 @@ def _same_set_tables(g, c):
     for col in ("ids", "cnt", "sig", "sig2", "orig", "size_start", "nlev", "plen", "cat", "filt", "seg", "seg_start", "post",
                 "post_start"):
         _same(getattr(g, col), getattr(c, col), col)
-    assert (g.vocab, tuple(g.post_sq)) == (c.vocab, tuple(c.post_sq))
+    assert (g.vocab, tuple(g.post_sq), g.post_row_bits) == (c.vocab, tuple(c.post_sq), c.post_row_bits)
 
 
 def _rand_ids(rng, n, width, vocab, kmax, allow_empty):
@@ -60,7 +60,17 @@ def test_set_table_raw(dev, width, kmax, vocab, side):
     g = tables.SetTable.from_padded(ids, side, dev, width=width, index=True)
     c = tables.SetTable.from_padded(ids, side, "cpu", width=width, index=True)
     assert g.post is not None and g.vocab == int(ids.max()) + 1 and g.post_sq[4] > 0
+    assert g.post_row_bits == c.post_row_bits == 32 - 2 * (width.bit_length() - 1) and g.post.element_size() == 4
     _same_set_tables(g, c)
+    tables.COMPACT_POSTINGS = False  # the 64-bit entries of tables with more rows than a 32-bit entry can name
+    try:
+        g64 = tables.SetTable.from_padded(ids, side, dev, width=width, index=True)
+        c64 = tables.SetTable.from_padded(ids, side, "cpu", width=width, index=True)
+    finally:
+        tables.COMPACT_POSTINGS = True
+    assert g64.post_row_bits == 0 and g64.post.element_size() == 8
+    _same_set_tables(g64, c64)
+    _same(g64.post_start, g.post_start, "post_start of both entry formats")
     rows = g.ids.cpu().numpy()
     live = rows >= 0
     assert (np.diff(np.where(live, rows, np.iinfo(np.int32).max).astype(np.int64), axis=1) >= 0).all()
