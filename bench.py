@@ -83,8 +83,9 @@ def parse_args():
     ap.add_argument("--threshold", type=float, default=None, help="override the workload's threshold (debug)")
     ap.add_argument("--id-range", type=int, default=0, help="c2 / c4: draw token ids from [0, N) instead of 2^17 (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--postings64", action="store_true",
-                    help="64-bit posting entries even where the 32-bit ones fit (A/B runs of the global-index kernels)")
+    ap.add_argument("--post-format", type=int, choices=(0, 1, 2), default=None,
+                    help="posting entries of the RAW tables' global index: 0 = 64 bits, 1 = 32 bits, 2 = 32 bits + signature "
+                         "fold (the default where the rows fit); A/B runs of the global-index kernel")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the exhaustive (prune off) run and c5w's second run at the score threshold (profiling passes)")
     ap.add_argument("--graph", type=int, default=0, help="1: replay each step as one captured hipGraph")
@@ -162,7 +163,7 @@ class Workload:
             self.launch_fn = self.lib.nsm_jaccard_raw_grid
             # the right table carries a global inverted index (tables.SetTable.from_padded): on these vocabularies the
             # library generates candidates from it at every threshold (csrc/jaccard_raw_global.hip)
-            self.kernel = self.kernel_match = "jaccard_raw_global_kernel<16"  # (<16, true>: 32-bit posting entries)
+            self.kernel = self.kernel_match = "jaccard_raw_global_kernel<16"  # (<16, 2>: entries with the signature fold)
             self.kernel_match_exhaustive = "jaccard_raw_kernel<16, false>"
             self.dtype = "int32"
             self.label = (f"{name.upper()}: {n}x{m} token-id sets/GPU (Poisson(8) ids, W=16), intersection_vs_union RAW, "
@@ -470,7 +471,7 @@ def global_index_bytes(work):
     toks = toks[toks < work.right.vocab]
     ps = work.right.post_start.cpu().numpy().astype(np.int64)
     visited = int((ps[5 * toks + cls_end] - ps[5 * toks]).sum())
-    entry_bytes = 4 if work.right.post_row_bits else 8  # (32-bit posting entries when the rows fit: nsm_hip.h, post)
+    entry_bytes = 4 if work.right.post_format == 1 else 8  # (nsm_hip.h, post: RAW tables carry 64-bit entries, format 0 or 2)
     return {"posting_entries_visited": visited, "probes": int(probe.sum()), "posting_entry_bytes": entry_bytes,
             "bytes": visited * entry_bytes + ids.shape[0] * (ids.shape[1] * 4 + 4) + int(probe.sum()) * 8}
 
@@ -1046,10 +1047,11 @@ def main():
     args = parse_args()
     import torch
 
-    if args.postings64:
+    if args.post_format is not None:
         from napkon_string_matching_amd import tables as _tables
 
-        _tables.COMPACT_POSTINGS = False
+        _tables.COMPACT_POSTINGS = args.post_format != 0
+        _tables.RAW_POST_FORMAT = args.post_format or 2
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

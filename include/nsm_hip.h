@@ -93,10 +93,16 @@ typedef struct nsm_hit {
  *      probe only meets rows of its own category --
  *   post        device uint64[n * width]    one entry per (row, id) sorted by (id, position p of the id in its row);
  *                                           entry = row | p << 32 | cnt << 40; the unused tail is zero
- *               or, with post_row_bits > 0 (ABI 5), device uint32[n * width]: entry = row | p << post_row_bits |
- *               (cnt - 1) << (post_row_bits + log2(width)) -- half the bytes of the kernels that live on posting-list
- *               bandwidth; possible when n <= 2^post_row_bits and post_row_bits + 2 log2(width) <= 32 (width 16: 16.7 M
- *               rows).  The caller picks the format (and sizes the column) before nsm_build_set_table fills it
+ *               (post_format 0).  ABI 5, tables with n <= 2^post_row_bits rows, post_row_bits + 2 log2(width) <= 32 (width
+ *               16: 16.7 M rows):
+ *                 post_format 1  device uint32[n * width]: entry = row | p << post_row_bits | (cnt - 1) << (post_row_bits +
+ *                                log2(width)) -- half the bytes; what a levels table's index needs (only the row is read);
+ *                 post_format 2  device uint64[n * width]: that 32-bit entry in the low word, and above it the 27-bit FOLD of
+ *                                the row's signature word (bit j = OR of sig bits j, j + 27, j + 54).  With c' = cnt -
+ *                                popcount(fold), |A n B| <= popcount(foldA & foldB) + min(c'A, c'B): the RAW grid decides
+ *                                most candidates from the entry alone instead of gathering their 8-byte signature words
+ *                                (64-byte sectors: two thirds of the HBM traffic of a 1M x 1M grid).
+ *               The caller picks the format (and sizes the column) before nsm_build_set_table fills it
  *   post_start  device int32 [5 * keys + 1]  (keys = vocab, or 64 vocab for a partitioned levels table) entries of key t
  *                                           with p < 1 / 2 / 4 / 8 / any are [post_start[5 t], post_start[5 t + 1 / 2 / 3 / 4 / 5])
  *   vocab       every id of the table is < vocab (checked by the builder)
@@ -123,7 +129,8 @@ typedef struct nsm_set_table {
   const uint64_t* post;
   const int32_t* post_start;
   uint64_t post_sq[5];
-  int32_t post_row_bits; /* 0: 64-bit posting entries; else 32-bit entries with this many row bits (see post) */
+  int32_t post_row_bits; /* row bits of the compact posting entry (post_format 1 and 2), else 0 */
+  int32_t post_format;   /* 0, 1 or 2: see post */
 } nsm_set_table;
 
 /* Code-unit string table of one side, rows sorted by `len` DESCENDING.

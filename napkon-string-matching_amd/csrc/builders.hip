@@ -290,12 +290,18 @@ __global__ void set_gather_kernel(const int32_t* __restrict__ perm, const int32_
 // (unused slots: all ones, sorted last), one radix sort, then the offsets: 5 boundaries per id (positions < 1, 2, 4, 8, any).
 __device__ __forceinline__ int post_class(int pos) { return pos < 1 ? 0 : pos < 2 ? 1 : pos < 4 ? 2 : pos < 8 ? 3 : 4; }
 
-// VAL = unsigned long long: entry = row | position << 32 | cnt << 40; VAL = uint32_t (row_bits > 0): the compact entry
-// row | position << row_bits | (cnt - 1) << (row_bits + log2 width)
-template <typename VAL>
+// FORMAT 0: entry = row | position << 32 | cnt << 40 (64 bits); 1: the compact entry row | position << row_bits |
+// (cnt - 1) << (row_bits + log2 width) (32 bits); 2: the compact entry with the 27-bit fold of the row's signature word above
+// it (64 bits; nsm_hip.h: post)
+__device__ __forceinline__ uint32_t sig_fold27(uint64_t sig) {
+  constexpr uint32_t kM = (1u << 27) - 1u;
+  return (static_cast<uint32_t>(sig) & kM) | (static_cast<uint32_t>(sig >> 27) & kM) | (static_cast<uint32_t>(sig >> 54) & 0xFu);
+}
+
+template <typename VAL, int FORMAT>
 __global__ void post_keys_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ cnt, const int32_t* __restrict__ seg,
-                                 int rows, int width, int vocab, int row_bits, int width_log, unsigned long long* __restrict__ keys,
-                                 VAL* __restrict__ vals, Status* st) {
+                                 const uint64_t* __restrict__ sig, int rows, int width, int vocab, int row_bits, int width_log,
+                                 unsigned long long* __restrict__ keys, VAL* __restrict__ vals, Status* st) {
   const long long s = static_cast<long long>(blockIdx.x) * kThreads + threadIdx.x;
   if (s >= static_cast<long long>(rows) * width) return;
   const int r = static_cast<int>(s / width), k = static_cast<int>(s % width);
@@ -310,11 +316,13 @@ __global__ void post_keys_kernel(const int32_t* __restrict__ ids, const int32_t*
       const unsigned long long tok = (seg ? static_cast<unsigned long long>(seg[r]) * static_cast<unsigned long long>(vocab) : 0ull) +
                                      static_cast<unsigned long long>(static_cast<uint32_t>(id));
       key = (tok << 8) | static_cast<unsigned long long>(k);
-      if constexpr (sizeof(VAL) == 8)
+      const uint32_t compact = static_cast<uint32_t>(r) | (static_cast<uint32_t>(k) << row_bits) |
+                               (static_cast<uint32_t>(c - 1) << (row_bits + width_log));
+      if constexpr (FORMAT == 0)
         val = static_cast<unsigned long long>(static_cast<uint32_t>(r)) | (static_cast<unsigned long long>(k) << 32) |
               (static_cast<unsigned long long>(c) << 40);
-      else
-        val = static_cast<uint32_t>(r) | (static_cast<uint32_t>(k) << row_bits) | (static_cast<uint32_t>(c - 1) << (row_bits + width_log));
+      else if constexpr (FORMAT == 1) val = compact;
+      else val = static_cast<unsigned long long>(compact) | (static_cast<unsigned long long>(sig_fold27(sig[r])) << 32);
     }
   }
   keys[s] = key;
@@ -617,11 +625,12 @@ extern "C" int nsm_build_set_table(const int32_t* ids_in, int32_t n, int32_t wid
       return NSM_E_BADARG;
     }
     const long long slots = static_cast<long long>(rows) * width;
-    const int row_bits = out->post_row_bits;
+    const int row_bits = out->post_row_bits, format = out->post_format;
     int width_log = 0;
     while ((1 << width_log) < width) ++width_log;
-    if (row_bits < 0 || (row_bits > 0 && (row_bits + 2 * width_log > 32 || (static_cast<long long>(rows) > (1ll << row_bits))))) {
-      set_error("%s: post_row_bits %d cannot hold %d rows of width %d in a 32-bit posting entry", who, row_bits, rows, width);
+    if (format < 0 || format > 2 || (format == 0) != (row_bits == 0) || row_bits < 0 ||
+        (row_bits > 0 && (row_bits + 2 * width_log > 32 || (static_cast<long long>(rows) > (1ll << row_bits))))) {
+      set_error("%s: post_format %d with post_row_bits %d cannot hold %d rows of width %d", who, format, row_bits, rows, width);
       return NSM_E_BADARG;
     }
     unsigned long long* keys = sc.get<unsigned long long>(slots);
@@ -637,14 +646,15 @@ extern "C" int nsm_build_set_table(const int32_t* ids_in, int32_t n, int32_t wid
     const size_t n_bounds = static_cast<size_t>(5 * n_keys + 1);
     (void)hipMemsetAsync(post_start, 0, n_bounds * sizeof(int32_t), stream);
     // (the entry type only changes the sort's value type and two stores)
-    auto fill = [&](auto* post) -> int {
+    auto fill = [&](auto* post, auto format_tag) -> int {
       using VAL = std::remove_pointer_t<decltype(post)>;
+      constexpr int kFormat = decltype(format_tag)::value;
       if (slots <= 0) return 0;
       VAL* vals = sc.get<VAL>(slots);
       if (sc.failed) return hip_status(hipErrorOutOfMemory, "builder scratch");
-      hipLaunchKernelGGL(post_keys_kernel<VAL>, blocks_for(slots), dim3(kThreads), 0, stream, out->ids, out->cnt,
-                         partition ? out->seg : static_cast<const int32_t*>(nullptr), rows, width, out->vocab, row_bits, width_log,
-                         keys, vals, d_status);
+      hipLaunchKernelGGL((post_keys_kernel<VAL, kFormat>), blocks_for(slots), dim3(kThreads), 0, stream, out->ids, out->cnt,
+                         partition ? out->seg : static_cast<const int32_t*>(nullptr), out->sig, rows, width, out->vocab, row_bits,
+                         width_log, keys, vals, d_status);
       size_t bytes = 0;
       hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, keys, keys_sorted, vals, post, static_cast<size_t>(slots), 0u,
                                                static_cast<unsigned>(bits), stream);
@@ -659,7 +669,10 @@ extern "C" int nsm_build_set_table(const int32_t* ids_in, int32_t n, int32_t wid
       return 0;
     };
     void* post_col = const_cast<void*>(static_cast<const void*>(out->post));
-    if (int rc = row_bits > 0 ? fill(static_cast<uint32_t*>(post_col)) : fill(static_cast<unsigned long long*>(post_col))) return rc;
+    if (int rc = format == 1   ? fill(static_cast<uint32_t*>(post_col), std::integral_constant<int, 1>{})
+                 : format == 2 ? fill(static_cast<unsigned long long*>(post_col), std::integral_constant<int, 2>{})
+                               : fill(static_cast<unsigned long long*>(post_col), std::integral_constant<int, 0>{}))
+      return rc;
     {
       size_t bytes = 0;
       hipError_t e = rocprim::inclusive_scan(nullptr, bytes, post_start, post_start, n_bounds, rocprim::maximum<int32_t>(), stream);

@@ -36,8 +36,9 @@ struct JacLevGlobalParams {
   unsigned long long cap;
 };
 
-// COMPACT: the right table's posting entries are 32 bits (the row in the low row_bits)
-template <int W, bool COMPACT>
+// FORMAT of the right table's posting entries (nsm_hip.h: post_format): 0 = 64 bits (the row in the low word), 1 = 32 bits and
+// 2 = 64 bits with the row in the low row_bits (this kernel reads nothing else of an entry)
+template <int W, int FORMAT>
 __global__ __launch_bounds__(kBlock) void jaccard_levels_global_kernel(
     const int32_t* __restrict__ lids, const int32_t* __restrict__ lcnt, const uint8_t* __restrict__ lplen,
     const uint32_t* __restrict__ lfilt, const int32_t* __restrict__ lorig, const int32_t* __restrict__ lseg,
@@ -110,10 +111,14 @@ __global__ __launch_bounds__(kBlock) void jaccard_levels_global_kernel(
         if (s_off[wave][mid] <= idx) seg = mid;
       }
       int rrow = 0;  // the posting entry's right row (position and size are not used here)
-      if constexpr (COMPACT) {
+      if constexpr (FORMAT == 1) {
         uint32_t e = 0u;
         if (live) e = reinterpret_cast<const uint32_t*>(post)[static_cast<size_t>(s_start[wave][seg]) + (idx - s_off[wave][seg])];
         rrow = static_cast<int>(e & ((1u << p.row_bits) - 1u));
+      } else if constexpr (FORMAT == 2) {
+        unsigned long long entry = 0ull;
+        if (live) entry = post[static_cast<size_t>(s_start[wave][seg]) + (idx - s_off[wave][seg])];
+        rrow = static_cast<int>(static_cast<uint32_t>(entry) & ((1u << p.row_bits) - 1u));
       } else {
         unsigned long long entry = 0ull;
         if (live) entry = post[static_cast<size_t>(s_start[wave][seg]) + (idx - s_off[wave][seg])];
@@ -232,14 +237,14 @@ int launch_levels_global(const nsm_set_table* l, const nsm_set_table* r, double 
   p.n_batches = (l->n + kRows - 1) / kRows;
   long long blocks = (p.n_batches + kWavesPerBlock - 1) / kWavesPerBlock;
   if (blocks > 256 * 8) blocks = 256 * 8;
-  if (p.row_bits > 0)
-    hipLaunchKernelGGL((jaccard_levels_global_kernel<W, true>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, l->ids,
-                       l->cnt, l->plen, l->filt, l->orig, l->seg, r->ids, r->plen, r->filt, r->orig,
-                       reinterpret_cast<const unsigned long long*>(r->post), r->post_start, hits, hit_count, p);
-  else
-    hipLaunchKernelGGL((jaccard_levels_global_kernel<W, false>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, l->ids,
-                       l->cnt, l->plen, l->filt, l->orig, l->seg, r->ids, r->plen, r->filt, r->orig,
-                       reinterpret_cast<const unsigned long long*>(r->post), r->post_start, hits, hit_count, p);
+#define NSM_LAUNCH_GLOBAL(F)                                                                                                     \
+  hipLaunchKernelGGL((jaccard_levels_global_kernel<W, F>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, l->ids, \
+                     l->cnt, l->plen, l->filt, l->orig, l->seg, r->ids, r->plen, r->filt, r->orig,                               \
+                     reinterpret_cast<const unsigned long long*>(r->post), r->post_start, hits, hit_count, p)
+  if (r->post_format == 2) NSM_LAUNCH_GLOBAL(2);
+  else if (r->post_format == 1) NSM_LAUNCH_GLOBAL(1);
+  else NSM_LAUNCH_GLOBAL(0);
+#undef NSM_LAUNCH_GLOBAL
   return hip_status(hipGetLastError(), "jaccard_levels_global_kernel launch");
 }
 

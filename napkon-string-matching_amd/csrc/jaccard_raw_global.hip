@@ -38,8 +38,22 @@ struct JacGlobalParams {
   uint8_t prefix[W + 4];    // P(size)
 };
 
-// COMPACT: the right table's posting entries are 32 bits (row | position << row_bits | (size - 1) << (row_bits + log2 W))
-template <int W, bool COMPACT>
+// 27-bit fold of a signature word's 58 hash bits (nsm_hip.h: sig): bit j = OR of the hash bits j, j + 27 and j + 54, i.e. the
+// signature of the same ids under (hash mod 27).  With c' = size - popcount(fold) (ids that share a bit inside their row),
+// |A n B| <= popcount(foldA & foldB) + min(c'A, c'B).  A fold that is all ones says nothing: its c' counts as the width.
+__host__ __device__ inline uint32_t sig_fold27(uint64_t sig) {
+  constexpr uint32_t kM = (1u << 27) - 1u;
+  return (static_cast<uint32_t>(sig) & kM) | (static_cast<uint32_t>(sig >> 27) & kM) | (static_cast<uint32_t>(sig >> 54) & 0xFu);
+}
+
+// FORMAT of the right table's posting entries (nsm_hip.h: post_format): 0 = 64 bits, row | position << 32 | size << 40;
+// 1 = 32 bits, row | position << row_bits | (size - 1) << (row_bits + log2 W); 2 = 64 bits, the 32-bit entry with the fold of
+// the row's signature word above it -- the entry alone then decides most candidates, and the 8-byte signature gather
+// (a 64-byte sector each: two thirds of configs[3]'s HBM traffic) is left to the few that pass
+#ifndef NSM_GLOBAL_PREFETCH
+#define NSM_GLOBAL_PREFETCH 1
+#endif
+template <int W, int FORMAT>
 __global__ __launch_bounds__(kBlock) void jaccard_raw_global_kernel(
     const int32_t* __restrict__ lids, const int32_t* __restrict__ lcnt, const uint64_t* __restrict__ lsig,
     const uint64_t* __restrict__ lsig2, const int32_t* __restrict__ lorig, const int32_t* __restrict__ rids,
@@ -104,31 +118,53 @@ __global__ __launch_bounds__(kBlock) void jaccard_raw_global_kernel(
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    // ---- lane = one candidate of the batch's flat list
-    for (int base = 0; base < total; base += kWave) {
+    // ---- lane = one candidate of the batch's flat list.  The kernel lives on the latency of the posting loads (one dependent
+    // round trip per 64 candidates, 8 waves per SIMD to hide it): the NEXT 64 entries are requested before this chunk's are
+    // looked at.
+    auto fetch = [&](int base, int& seg, bool& live) -> unsigned long long {
       const int idx = base + lane;
-      const bool live = idx < total;
-      int seg = 0;  // the last segment that starts at or before idx (empty segments share their successor's offset)
+      live = idx < total;
+      seg = 0;  // the last segment that starts at or before idx (empty segments share their successor's offset)
 #pragma unroll
       for (int step = kWave / 2; step > 0; step >>= 1) {
         const int mid = seg + step;
         if (s_off[wave][mid] <= idx) seg = mid;
       }
+      const size_t at = static_cast<size_t>(s_start[wave][seg]) + (idx - s_off[wave][seg]);
+      unsigned long long raw = 0ull;
+      if (live) {
+        if constexpr (FORMAT == 1) raw = reinterpret_cast<const uint32_t*>(post)[at];
+        else raw = post[at];
+      }
+      return raw;
+    };
+    int seg_n = 0;
+    bool live_n = false;
+    unsigned long long raw_n = fetch(0, seg_n, live_n);
+    for (int base = 0; base < total; base += kWave) {
+#if !NSM_GLOBAL_PREFETCH  // (A/B builds)
+      if (base > 0) raw_n = fetch(base, seg_n, live_n);
+#endif
+      const int seg = seg_n;
+      const bool live = live_n;
+      const unsigned long long raw = raw_n;
+#if NSM_GLOBAL_PREFETCH
+      if (base + kWave < total) raw_n = fetch(base + kWave, seg_n, live_n);
+#endif
       // the posting entry: right row, position of the probed id in it, its size
       int rrow, pb, b;
-      if constexpr (COMPACT) {
+      uint32_t fold_b = 0u;
+      if constexpr (FORMAT != 0) {
         constexpr int kLogW = W == 16 ? 4 : W == 32 ? 5 : 6;
-        uint32_t e = 0u;
-        if (live) e = reinterpret_cast<const uint32_t*>(post)[static_cast<size_t>(s_start[wave][seg]) + (idx - s_off[wave][seg])];
+        const uint32_t e = static_cast<uint32_t>(raw);
+        fold_b = static_cast<uint32_t>(raw >> 32);
         rrow = static_cast<int>(e & ((1u << p.row_bits) - 1u));
         pb = static_cast<int>((e >> p.row_bits) & (W - 1));
         b = live ? static_cast<int>((e >> (p.row_bits + kLogW)) & (W - 1)) + 1 : 0;
       } else {
-        unsigned long long entry = 0ull;
-        if (live) entry = post[static_cast<size_t>(s_start[wave][seg]) + (idx - s_off[wave][seg])];
-        rrow = static_cast<int>(static_cast<uint32_t>(entry));
-        pb = static_cast<int>((entry >> 32) & 0xffu);
-        b = static_cast<int>((entry >> 40) & 0xffu);
+        rrow = static_cast<int>(static_cast<uint32_t>(raw));
+        pb = static_cast<int>((raw >> 32) & 0xffu);
+        b = static_cast<int>((raw >> 40) & 0xffu);
       }
       const int meta = s_meta[wave][seg];
       const int pa = meta & 0xff, la = meta >> 8;
@@ -136,6 +172,12 @@ __global__ __launch_bounds__(kBlock) void jaccard_raw_global_kernel(
       // entry alone: right prefix, size filter, positional bound (the probed id as the FIRST common one: at most
       // 1 + what follows it on either side can be common)
       bool ok = live && pb < s_prefix[b] && need <= min(la, b) && 1 + min(la - pa - 1, b - pb - 1) >= need;
+      if constexpr (FORMAT == 2) {  // the folded signatures of both rows: no memory access
+        constexpr uint32_t kM = (1u << 27) - 1u;
+        const uint32_t fold_a = sig_fold27(s_sig[wave][seg]);
+        const int ca = fold_a == kM ? W : la - __popc(fold_a), cb = fold_b == kM ? W : b - __popc(fold_b);
+        ok = ok && __popc(fold_a & fold_b) + min(ca, cb) >= need;
+      }
       if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue;
       if (ok) {
         const uint64_t sr = rsig[rrow] | kCollBits;
@@ -234,14 +276,14 @@ int launch_raw_global(const nsm_set_table* l, const nsm_set_table* r, double thr
   if (probe_only || longest == 0) return 0;  // (longest == 0: no pair of sizes can reach the threshold)
   long long blocks = (p.n_batches + kWavesPerBlock - 1) / kWavesPerBlock;
   if (blocks > 256 * 8) blocks = 256 * 8;
-  if (p.row_bits > 0)
-    hipLaunchKernelGGL((jaccard_raw_global_kernel<W, true>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, l->ids,
-                       l->cnt, l->sig, (l->sig2 && r->sig2) ? l->sig2 : nullptr, l->orig, r->ids, r->sig, r->sig2, r->orig,
-                       reinterpret_cast<const unsigned long long*>(r->post), r->post_start, hits, hit_count, p);
-  else
-    hipLaunchKernelGGL((jaccard_raw_global_kernel<W, false>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, l->ids,
-                       l->cnt, l->sig, (l->sig2 && r->sig2) ? l->sig2 : nullptr, l->orig, r->ids, r->sig, r->sig2, r->orig,
-                       reinterpret_cast<const unsigned long long*>(r->post), r->post_start, hits, hit_count, p);
+#define NSM_LAUNCH_GLOBAL(F)                                                                                                  \
+  hipLaunchKernelGGL((jaccard_raw_global_kernel<W, F>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, l->ids, \
+                     l->cnt, l->sig, (l->sig2 && r->sig2) ? l->sig2 : nullptr, l->orig, r->ids, r->sig, r->sig2, r->orig,     \
+                     reinterpret_cast<const unsigned long long*>(r->post), r->post_start, hits, hit_count, p)
+  if (r->post_format == 2) NSM_LAUNCH_GLOBAL(2);
+  else if (r->post_format == 1) NSM_LAUNCH_GLOBAL(1);
+  else NSM_LAUNCH_GLOBAL(0);
+#undef NSM_LAUNCH_GLOBAL
   return hip_status(hipGetLastError(), "jaccard_raw_global_kernel launch");
 }
 

@@ -48,6 +48,7 @@ class NsmSetTable(ctypes.Structure):
         ("post_start", ctypes.c_void_p),
         ("post_sq", ctypes.c_uint64 * 5),
         ("post_row_bits", ctypes.c_int32),
+        ("post_format", ctypes.c_int32),
     ]
 
 

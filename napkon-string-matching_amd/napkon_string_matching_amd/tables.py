@@ -53,6 +53,7 @@ def _id_limit(orig, n: int) -> int:
 
 
 COMPACT_POSTINGS = True  # (tests switch it off to cover the 64-bit entries at small sizes)
+RAW_POST_FORMAT = 2      # compact posting entries of RAW tables: 2 = with the signature fold, 1 = 32 bits (A/B runs)
 
 
 def post_row_bits(rows: int, width: int) -> int:
@@ -62,10 +63,20 @@ def post_row_bits(rows: int, width: int) -> int:
     return bits if (COMPACT_POSTINGS and rows <= (1 << bits)) else 0
 
 
-def inverted_index(ids: np.ndarray, cnt: np.ndarray, vocab: int, seg: Optional[np.ndarray] = None, row_bits: int = 0):
+def sig_fold27(sig: np.ndarray) -> np.ndarray:
+    """27-bit fold of signature words (bit j = OR of the hash bits j, j + 27, j + 54): what posting entries of format 2 carry."""
+    s = np.asarray(sig, dtype=np.uint64)
+    m = np.uint64((1 << 27) - 1)
+    return ((s & m) | ((s >> np.uint64(27)) & m) | ((s >> np.uint64(54)) & np.uint64(0xF))).astype(np.uint32)
+
+
+def inverted_index(ids: np.ndarray, cnt: np.ndarray, vocab: int, seg: Optional[np.ndarray] = None, row_bits: int = 0,
+                   sig: Optional[np.ndarray] = None):
     """The global inverted index of a set table (include/nsm_hip.h: post / post_start / post_sq), the numpy way --
     what ``nsm_build_set_table`` builds on the GPU, byte for byte.  ``ids`` [n][W] (RAW: ascending per row), ``cnt`` [n];
-    ``seg`` [n]: a partitioned levels table keys its postings by (category segment, id); ``row_bits`` > 0: 32-bit entries."""
+    ``seg`` [n]: a partitioned levels table keys its postings by (category segment, id).  Entry format (``post_format``):
+    0 = 64 bits (``row_bits`` 0); 1 = 32 bits (``row_bits`` > 0); 2 = 64 bits, the 32-bit entry with the fold of the row's
+    signature word above it (``row_bits`` > 0 and ``sig`` given)."""
     n, width = ids.shape
     valid = np.arange(width, dtype=np.int64)[None, :] < np.asarray(cnt, dtype=np.int64)[:, None]
     r_idx, k_idx = np.nonzero(valid)  # row-major: the stable sort below keeps rows ascending inside one (id, position)
@@ -81,6 +92,9 @@ def inverted_index(ids: np.ndarray, cnt: np.ndarray, vocab: int, seg: Optional[n
         entry = (r_idx.astype(np.uint32) | (k_idx.astype(np.uint32) << np.uint32(row_bits)) |
                  ((np.asarray(cnt, dtype=np.uint32)[r_idx] - np.uint32(1)) << np.uint32(row_bits + wl)))
         post = np.zeros(n * width, dtype=np.uint32)
+        if sig is not None:
+            entry = entry.astype(np.uint64) | (sig_fold27(sig)[r_idx].astype(np.uint64) << np.uint64(32))
+            post = np.zeros(n * width, dtype=np.uint64)
     else:
         entry = (r_idx.astype(np.uint64) | (k_idx.astype(np.uint64) << np.uint64(32)) |
                  (np.asarray(cnt, dtype=np.uint64)[r_idx] << np.uint64(40)))
@@ -252,7 +266,8 @@ class SetTable:
     post_start: Optional[torch.Tensor] = None
     vocab: int = 0
     post_sq: Tuple[int, ...] = (0, 0, 0, 0, 0)
-    post_row_bits: int = 0  # > 0: ``post`` holds 32-bit entries with this many row bits (``post_row_bits(rows, width)``)
+    post_row_bits: int = 0  # > 0: compact posting entries with this many row bits (``post_row_bits(rows, width)``)
+    post_format: int = 0  # 0: 64-bit entries; 1: 32-bit (levels tables); 2: 64-bit with the signature fold (RAW tables)
     id_limit: int = 0  # every ``orig`` entry is below it (the sort's key width, nsm_sort_hits); 0 = unknown
 
     # ------------------------------------------------------------------ builders
@@ -499,11 +514,13 @@ class SetTable:
         post = post_start = None
         post_sq = (0, 0, 0, 0, 0)
         row_bits = post_row_bits(n, width) if index_vocab else 0
+        fmt = 0 if not row_bits else (1 if nlev is not None else RAW_POST_FORMAT)
         if index_vocab:
-            post, post_start, post_sq = inverted_index(ids, cnt_s, index_vocab, seg=seg, row_bits=row_bits)
+            post, post_start, post_sq = inverted_index(ids, cnt_s, index_vocab, seg=seg, row_bits=row_bits,
+                                                       sig=sig1 if fmt == 2 else None)
         return cls(
-            post=None if post is None else _dev(post.view(np.int32 if row_bits else np.int64), device),
-            post_row_bits=row_bits,
+            post=None if post is None else _dev(post.view(np.int32 if fmt == 1 else np.int64), device),
+            post_row_bits=row_bits, post_format=fmt,
             post_start=None if post_start is None else _dev(post_start, device), vocab=int(index_vocab), post_sq=post_sq,
             filt=None if filt is None else _dev(filt, device),
             ids=_dev(ids, device),
@@ -562,8 +579,9 @@ class SetTable:
             filt=new((cap, 8), torch.int32) if levels else None,
             max_levels=max_levels, seg=new(cap, torch.int32) if do_part else None,
             seg_start=new(65, torch.int32) if do_part else None, category_mode=out_mode if levels else None,
-            post=new(cap * width, torch.int32 if post_row_bits(rows, width) else torch.int64) if index_vocab else None,
+            post=new(cap * width, torch.int32 if (post_row_bits(rows, width) and (levels or RAW_POST_FORMAT == 1)) else torch.int64) if index_vocab else None,
             post_row_bits=post_row_bits(rows, width) if index_vocab else 0,
+            post_format=(0 if not post_row_bits(rows, width) else 1 if levels else RAW_POST_FORMAT) if index_vocab else 0,
             post_start=new(5 * index_vocab * (64 if do_part else 1) + 1, torch.int32) if index_vocab else None,
             vocab=int(index_vocab),
         )
@@ -596,6 +614,7 @@ class SetTable:
             ptr(self.plen),
             ptr(self.cat), ptr(self.filt), ptr(self.seg), ptr(self.seg_start), self.n, self.width, self.max_levels,
             self.vocab, ptr(self.post), ptr(self.post_start), (ctypes.c_uint64 * 5)(*self.post_sq), self.post_row_bits,
+            self.post_format,
         )
 
     def nbytes(self) -> int:

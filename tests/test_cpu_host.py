@@ -97,17 +97,23 @@ def test_set_table_encoding_cpu():
     assert row0[:3] == [2, 5, 9] and set(row0[3:]) == {-2}  # RAW rows: ids ascending (the inverted index's global order)
     # right tables carry the global inverted index: one entry per (row, id) sorted by (id, position), 5 offsets per id
     assert t.vocab == 10 and t.post_start.shape[0] == 51 and t.post_sq == (2, 4, 5, 5, 5)
-    # 3 rows of width 16: 32-bit entries, row | position << 24 | (size - 1) << 28
-    assert t.post_row_bits == 24 and t.post.dtype == torch.int32
-    entries = [(int(e) & 0xFFFFFF, (int(e) >> 24) & 0xF, ((int(e) >> 28) & 0xF) + 1) for e in t.post[:5].numpy().view(np.uint32)]
+    # 3 rows of width 16, RAW: format 2 -- row | position << 24 | (size - 1) << 28 in the low word, above it the 27-bit fold of
+    # the row's signature word
+    assert t.post_row_bits == 24 and t.post_format == 2 and t.post.dtype == torch.int64
+    raw = t.post[:5].numpy().view(np.uint64)
+    entries = [(int(e) & 0xFFFFFF, (int(e) >> 24) & 0xF, ((int(e) >> 28) & 0xF) + 1) for e in raw]
     want = [(0, 0, 3), (0, 1, 3), (1, 0, 2), (1, 1, 2), (0, 2, 3)]  # ids 2, 5, 7, 8, 9 -> (row, position, size)
     assert entries == want
+    folds = tables.sig_fold27(t.sig.numpy().view(np.uint64))
+    assert [int(e) >> 32 for e in raw] == [int(folds[r]) for r, _, _ in want]
+    sg = int(t.sig.numpy().view(np.uint64)[0])  # the fold keeps every hash bit: same ids, hash taken mod 27
+    assert int(folds[0]) == ((sg & ((1 << 27) - 1)) | ((sg >> 27) & ((1 << 27) - 1)) | ((sg >> 54) & 0xF)) and 1 <= bin(int(folds[0])).count("1") <= 3
     tables.COMPACT_POSTINGS = False  # the 64-bit entries of tables with too many rows: row | position << 32 | size << 40
     try:
         t64 = tables.SetTable.from_padded(ids, "right", "cpu")
     finally:
         tables.COMPACT_POSTINGS = True
-    assert t64.post_row_bits == 0 and t64.post.dtype == torch.int64
+    assert t64.post_row_bits == 0 and t64.post_format == 0 and t64.post.dtype == torch.int64
     assert [(int(e) & 0xFFFFFFFF, (int(e) >> 32) & 0xFF, (int(e) >> 40) & 0xFF) for e in t64.post[:5].numpy().view(np.uint64)] == want
     assert t64.post_start.tolist() == t.post_start.tolist() and t64.post_sq == t.post_sq
     assert tables.post_row_bits(1 << 24, 16) == 24 and tables.post_row_bits((1 << 24) + 1, 16) == 0 and tables.post_row_bits(1 << 20, 64) == 20

@@ -31,7 +31,7 @@ def _same_set_tables(g, c):
     for col in ("ids", "cnt", "sig", "sig2", "orig", "size_start", "nlev", "plen", "cat", "filt", "seg", "seg_start", "post",
                 "post_start"):
         _same(getattr(g, col), getattr(c, col), col)
-    assert (g.vocab, tuple(g.post_sq), g.post_row_bits) == (c.vocab, tuple(c.post_sq), c.post_row_bits)
+    assert (g.vocab, tuple(g.post_sq), g.post_row_bits, g.post_format) == (c.vocab, tuple(c.post_sq), c.post_row_bits, c.post_format)
 
 
 def _rand_ids(rng, n, width, vocab, kmax, allow_empty):
@@ -60,7 +60,7 @@ def test_set_table_raw(dev, width, kmax, vocab, side):
     g = tables.SetTable.from_padded(ids, side, dev, width=width, index=True)
     c = tables.SetTable.from_padded(ids, side, "cpu", width=width, index=True)
     assert g.post is not None and g.vocab == int(ids.max()) + 1 and g.post_sq[4] > 0
-    assert g.post_row_bits == c.post_row_bits == 32 - 2 * (width.bit_length() - 1) and g.post.element_size() == 4
+    assert g.post_row_bits == c.post_row_bits == 32 - 2 * (width.bit_length() - 1) and g.post_format == 2  # (RAW: entry + signature fold)
     _same_set_tables(g, c)
     tables.COMPACT_POSTINGS = False  # the 64-bit entries of tables with more rows than a 32-bit entry can name
     try:
@@ -68,7 +68,7 @@ def test_set_table_raw(dev, width, kmax, vocab, side):
         c64 = tables.SetTable.from_padded(ids, side, "cpu", width=width, index=True)
     finally:
         tables.COMPACT_POSTINGS = True
-    assert g64.post_row_bits == 0 and g64.post.element_size() == 8
+    assert g64.post_row_bits == 0 and g64.post_format == 0
     _same_set_tables(g64, c64)
     _same(g64.post_start, g.post_start, "post_start of both entry formats")
     rows = g.ids.cpu().numpy()

@@ -121,13 +121,13 @@ def test_jaccard_raw_global_index(dev, width, kmax, vocab, n_left, n_right):
     assert rt.post is not None and lt.post is None and rt.vocab == int(np.max(right)) + 1
     plain = tables.SetTable.from_padded(right, "right", dev, width=width, index=False)
     assert plain.post is None
-    assert rt.post_row_bits > 0  # 32-bit posting entries; the 64-bit ones of tables with too many rows for them:
+    assert rt.post_row_bits > 0 and rt.post_format == 2  # compact entries with the signature fold; the plain 64-bit ones:
     tables.COMPACT_POSTINGS = False
     try:
         rt64 = tables.SetTable.from_padded(right, "right", dev, width=width)
     finally:
         tables.COMPACT_POSTINGS = True
-    assert rt64.post_row_bits == 0 and rt64.post.element_size() == 8
+    assert rt64.post_row_bits == 0 and rt64.post_format == 0
     for thr in (0.01, 0.1, 0.25, 1 / 3, 0.5, 0.6, 0.75, 0.8, 0.9, 1.0):
         want = native.jaccard_raw(native.csr_from_padded(left), native.csr_from_padded(right), thr, cap=1 << 20)
         forced = grid.jaccard_raw_grid(lt, rt, thr, index=True, capacity=1 << 12)
@@ -447,7 +447,7 @@ def test_jaccard_levels_random(dev, vocab, max_levels, max_new):
                                                category_mode=mode, partition=partition)
         finally:
             tables.COMPACT_POSTINGS = True
-        assert rt.post_row_bits > 0 and rt64.post_row_bits == 0
+        assert rt.post_format == 1 and rt.post.element_size() == 4 and rt64.post_format == 0  # (levels tables: 32-bit entries)
         assert (lt.seg is not None) == (partition and mode != _lib.CAT_NONE)
         for thr in (0.0, 0.1, 0.3, 0.6, 0.8, 0.93):
             want = native.levels(False, left, right, thr, lcat, rcat, mode, cap=1 << 17)
