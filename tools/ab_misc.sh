@@ -1,6 +1,8 @@
 #!/bin/bash
-# scratch GPU call -> gpurun_out/misc/
+# fuzz campaigns at the current kernels -> gpurun_out/fuzz/
 set -e
-mkdir -p gpurun_out/misc
-timeout -k 10 1100 python -m pytest tests/test_gpu_builders.py tests/test_gpu_grids.py tests/test_gpu_wide.py tests/test_gpu_api.py -q -x > gpurun_out/misc/tests.txt 2>&1 || { tail -40 gpurun_out/misc/tests.txt; exit 1; }
-tail -3 gpurun_out/misc/tests.txt
+mkdir -p gpurun_out/fuzz
+timeout -k 10 560 python tools/fuzz_parity.py --seconds 480 --seed 40000 > gpurun_out/fuzz/parity.txt 2>&1 || { tail -20 gpurun_out/fuzz/parity.txt; exit 1; }
+tail -2 gpurun_out/fuzz/parity.txt
+timeout -k 10 460 python tools/fuzz_api.py --seconds 380 --seed 50000 > gpurun_out/fuzz/api.txt 2>&1 || { tail -20 gpurun_out/fuzz/api.txt; exit 1; }
+tail -2 gpurun_out/fuzz/api.txt

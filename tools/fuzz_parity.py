@@ -81,6 +81,10 @@ def main():
             print(json.dumps({"progress": counts, "round_seed": rnd}), flush=True)
             next_report += 60.0
         rng = random.Random(rnd)
+        # posting entries of the global inverted index (include/nsm_hip.h: post_format): every format gets its share
+        fmt_rng = random.Random(rnd * 7919 + 1)
+        tables.COMPACT_POSTINGS = fmt_rng.random() < 0.8
+        tables.RAW_POST_FORMAT = fmt_rng.choice([1, 2, 2])
         family = rng.choice(["jaccard_raw", "indel_raw", "jaccard_levels", "indel_levels", "indel_levels", "indel_split", "wide"])
         counts[family] = counts.get(family, 0) + 1
         thr = rng.choice(thresholds)
