@@ -3,14 +3,18 @@
 // builds Python sets of any size, :27 hands strings of any length to rapidfuzz), so a drop-in must not refuse them; they
 // are rare in NAPKON data (a very long option list, a questionnaire in another script), so the host routes ONLY the
 // items that need it through here (napkon_string_matching_amd/wide.py) and everything else stays on the fast kernels.
-// No pruning: every pair that passes the category predicate is scored in full, in the reference's operation order.
+// Scores are accumulated in the reference's operation order.  One exact prune (round 4): LCS <= min(la, lb) bounds every
+// step's ratio from the lengths alone, so a pair whose weighted bound stays below the threshold is dropped before any LCS
+// runs, a lane dies as soon as its score so far plus the bound of the remaining steps cannot reach it, and a row none of
+// whose lanes is alive is skipped.
 //
 //   nsm_indel_any_grid    compare_terms x fuzzy_match (or the RAW ratio) on CSR strings of 16-bit code units.
 //       lane = right item, left item wave-uniform.  Bit-parallel LCS (Hyyro) with the PATTERN cut into chunks of 128
 //       code units (4 limbs of 32 bits): chunk c is run over the lane's whole text with the carry of the multi-word add
 //       handed from chunk c - 1 to chunk c through one bit per text position (carries only travel upwards, so the chunks
 //       can be run one after the other).  Match masks of a chunk: one LDS table of 4 limbs per symbol.
-//   nsm_jaccard_any_grid  compare_terms x intersection_vs_union (or the RAW quotient) on CSR id lists sorted by id, each id
+//   nsm_jaccard_any_grid  (the same kind of bound from the set sizes: |A n B| <= min, |A u B| >= max)
+//       compare_terms x intersection_vs_union (or the RAW quotient) on CSR id lists sorted by id, each id
 //       with the first level that contains it: a two-pointer merge per pair finds the common ids, a per-lane histogram of
 //       "first step that has it on both sides" gives every step's |A n B| as a prefix sum.
 #include "nsm_common.hpp"
@@ -77,7 +81,23 @@ __global__ __launch_bounds__(kWave) void indel_any_kernel(
     ok = ok && lr > 0;
     const int S = p.raw ? 1 : max(ll, lr);
     const int s_hi = p.raw ? 1 : max(ll, lr_max);
-    double score = 0.0, ratio = 0.0, factor = 1.0;
+    // ---- length bound of the whole pair: sum of 2^-s x ratio(la, lb, LCS = min(la, lb)) -- the same expression the score
+    // is built from, with an LCS that is never smaller, accumulated in the same order (every operation is monotone)
+    double ub_rest = 0.0;
+    if (ok) {
+      double f = 1.0;
+      for (int s = p.raw ? 0 : 1; s <= (p.raw ? 0 : S); ++s) {
+        f *= 0.5;
+        const int a = max(0, min(s, ll - 1)), b = max(0, min(s, lr - 1));
+        const int la = static_cast<int>(loff[lf + a + 1] - loff[lf + a]), lb = static_cast<int>(roff[rr0 + b + 1] - roff[rr0 + b]);
+        const double ub = any_indel_score(la, lb, min(la, lb));
+        ub_rest = p.raw ? ub : ub_rest + ub * f;
+      }
+    }
+    constexpr double kSlack = 1e-9;  // (the bound is subtracted step by step below: rounding, far above 2^-52)
+    ok = ok && ub_rest + kSlack >= p.threshold;
+    if (!__any(ok)) continue;
+    double score = 0.0, ratio = 0.0, factor = 1.0, ub_cur = 0.0;
     int prev_a = -1, prev_b = -1;
     for (int s = p.raw ? 0 : 1; s <= (p.raw ? 0 : s_hi); ++s) {
       factor *= 0.5;
@@ -134,11 +154,19 @@ __global__ __launch_bounds__(kWave) void indel_any_kernel(
         }
         if (fresh) {
           ratio = any_indel_score(la, lb, zeros);
+          ub_cur = any_indel_score(la, lb, min(la, lb));
           prev_a = a;
           prev_b = b;
         }
       }
-      if (run) score = p.raw ? ratio : score + ratio * factor;
+      if (run) {
+        score = p.raw ? ratio : score + ratio * factor;
+        // what the steps still to come can add at most; a lane that cannot reach the threshold any more stops (its score
+        // is then below the threshold whatever follows: no hit is lost)
+        ub_rest = p.raw ? 0.0 : ub_rest - ub_cur * factor;
+        if (s < S && score + ub_rest + kSlack < p.threshold) ok = false;
+      }
+      if (!__any(ok)) break;
     }
     emit_hits_wave(hits, p.cap, count, ok && score >= p.threshold, score, lorig[i], rorig[jc]);
   }
@@ -181,6 +209,19 @@ __global__ __launch_bounds__(kWave) void jaccard_any_kernel(
       // every step's two level rows are merged on their own (lane-local): nothing is assumed about how the levels of an
       // item relate, and an item may have any number of them
       double score = 0.0, factor = 1.0, q = 0.0;
+      if (ok) {  // size bound of the whole pair: |A n B| <= min, |A u B| >= max at every step
+        const int lf = lfirst[i];
+        const int S = p.raw ? 0 : max(ll, lr);
+        double ub = 0.0, f = 1.0;
+        for (int s = p.raw ? 0 : 1; s <= S; ++s) {
+          f *= 0.5;
+          const int a = max(0, min(s, ll - 1)), b = max(0, min(s, lr - 1));
+          const int na = static_cast<int>(loff[lf + a + 1] - loff[lf + a]), nb2 = static_cast<int>(roff[rf + b + 1] - roff[rf + b]);
+          const double qb = max(na, nb2) > 0 ? static_cast<double>(min(na, nb2)) / static_cast<double>(max(na, nb2)) : 0.0;
+          ub = p.raw ? qb : ub + qb * f;
+        }
+        ok = ub + 1e-9 >= p.threshold;
+      }
       if (ok) {
         const int lf = lfirst[i];
         const int S = p.raw ? 0 : max(ll, lr);
@@ -220,6 +261,21 @@ __global__ __launch_bounds__(kWave) void jaccard_any_kernel(
     const long long la0 = loff[i];
     const int na = static_cast<int>(loff[i + 1] - la0);
     const int S = p.raw ? 1 : max(ll, lr);
+    if (ok) {  // size bound of the whole pair (|A n B| <= min, |A u B| >= max at every step): no merge for the rest
+      double ub = 0.0, f = 1.0;
+      if (p.raw) {
+        ub = max(na, nb) > 0 ? static_cast<double>(min(na, nb)) / static_cast<double>(max(na, nb)) : 0.0;
+      } else {
+        for (int s = 1; s <= S; ++s) {
+          f *= 0.5;
+          const int ca = lplen[static_cast<size_t>(i) * max_levels + min(s, ll - 1)];
+          const int cb = rplen[static_cast<size_t>(jc) * max_levels + min(s, lr - 1)];
+          ub += (max(ca, cb) > 0 ? static_cast<double>(min(ca, cb)) / static_cast<double>(max(ca, cb)) : 0.0) * f;
+        }
+      }
+      ok = ub + 1e-9 >= p.threshold;
+    }
+    if (!__any(ok)) continue;
     for (int s = 0; s <= kAnyMaxLevels; ++s) s_first[s * kWave + lane] = 0;
     if (ok) {  // two-pointer merge of the id lists (both sorted by id, unique per item)
       int x = 0, y = 0;

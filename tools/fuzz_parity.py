@@ -24,6 +24,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=300.0)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--family", default=None, help="only this kernel family (jaccard_raw, indel_raw, jaccard_levels, indel_levels, indel_split, wide)")
     args = ap.parse_args()
 
     import numpy as np
@@ -86,6 +87,8 @@ def main():
         tables.COMPACT_POSTINGS = fmt_rng.random() < 0.8
         tables.RAW_POST_FORMAT = fmt_rng.choice([1, 2, 2])
         family = rng.choice(["jaccard_raw", "indel_raw", "jaccard_levels", "indel_levels", "indel_levels", "indel_split", "wide"])
+        if args.family:
+            family = args.family
         counts[family] = counts.get(family, 0) + 1
         thr = rng.choice(thresholds)
         n, m = rng.randint(1, 400), rng.randint(1, 600)
