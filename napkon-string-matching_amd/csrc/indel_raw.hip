@@ -82,42 +82,34 @@ __device__ __forceinline__ void raw_build_masks(unsigned long long* pm, int pm_s
   __builtin_amdgcn_wave_barrier();
 }
 
-// LCS of the pattern whose match masks are in the wave's table (LDS byte offset pm_base) against text row j, lean form of
-// the pruning kernels: 16 code units of the text per global load, addresses computed on the fly, no register outlives it.
-__device__ __forceinline__ int raw_lcs_lean(const uint8_t* __restrict__ rcodes, int j, uint32_t pm_base, bool wide, int npairs) {
-  const uint4* tp = reinterpret_cast<const uint4*>(rcodes + static_cast<size_t>(j) * 64);
-  const uint32_t hsel = wide ? 0u : 4u;
-  const int nchars = 2 * npairs;
-  uint32_t v32 = ~0u;
-  unsigned long long v64 = ~0ull;
-  for (int q = 0; q < 4; ++q) {
-    if (q * 16 >= nchars) break;
-    const uint4 t4 = tp[q];
-    const uint32_t w[4] = {t4.x, t4.y, t4.z, t4.w};
+// LCS of ONE pair (left row `row` of `la`, right row `j` of `lb` code units; all wave-uniform) on the SCALAR unit: lane k
+// holds code unit k of both strings (two 64-byte loads), v_readlane hands the right string's units to the scalar unit one
+// by one, and per unit c the match mask is a ballot -- M = lanes whose left unit equals c -- so the recurrence
+// V' = (V + (V & M)) | (V & ~M) runs on one 64-bit scalar: a v_readlane, a v_cmp and five SALU ops per code unit, no mask
+// table, no LDS, 50 VGPRs for the whole kernel.  (The wave-wide form scores 64 texts against one pattern; with one surviving
+// pair per pattern -- 4.1e5 of them per configs[2] grid -- 63 of its 64 lanes computed nothing: 0.9 of 4.2 ms, and its 32
+// address registers set the kernel's occupancy.)
+__device__ __forceinline__ int raw_lcs_pair(const uint8_t* __restrict__ lcodes, int row, int la, const uint8_t* __restrict__ rcodes,
+                                            int j, int lb, int lane) {
+  // lanes past the pattern hold a value no code unit equals, so the right string's padding (code = alphabet, like the left
+  // string's own) matches nothing and whole words can be processed without a per-unit length test
+  const uint32_t code = lcodes[static_cast<size_t>(row) * 64 + lane];
+  const uint32_t pat = lane < la ? code : 0x100u;
+  const uint32_t text = rcodes[static_cast<size_t>(j) * 64 + lane];
+  unsigned long long v = ~0ull;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      uint32_t addr[4];
+  for (int w = 0; w < 16; ++w) {
+    if (4 * w < lb) {  // (wave-uniform; no `break`: the loop must unroll)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const uint32_t c = (w[e] >> (8 * k)) & 0xffu;
-        addr[k] = pm_base + 8 * c + (((c >> 4) & 1u) ? hsel : 0u);
-      }
-      if (!wide) {
-        uint32_t m[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) m[k] = lds_load<uint32_t>(addr[k]);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v32 = lcs_step32(v32, m[k]);
-      } else {
-        unsigned long long m[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) m[k] = lds_load<unsigned long long>(addr[k]);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v64 = lcs_step64(v64, m[k]);
+      for (int b = 0; b < 4; ++b) {
+        const uint32_t c = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(text), 4 * w + b));
+        const unsigned long long m = __ballot(pat == c);
+        const unsigned long long u = v & m;
+        v = (v + u) | (v & ~m);
       }
     }
   }
-  return wide ? 64 - __popcll(v64) : 32 - __popc(v32);
+  return __popcll(~v);
 }
 
 #ifndef NSM_C3_OCC
@@ -169,11 +161,11 @@ __global__ __launch_bounds__(kBlock) NSM_C3_OCC void indel_raw_kernel(
   // therefore stored in BOTH halves of its entry and symbol c is read from half (c >> 4) & 1: symbols 0..31
   // map to 32 different banks.  The half is baked into the text's addresses, which are rebuilt when the
   // pattern class changes between wide and narrow (rows are sorted by length: once per chunk).
-  // PRUNE = false (every row runs the LCS): the text is unpacked once into 32 registers, below.  PRUNE = true: LCS rows
-  // are rare (< 0.1 % of the rows a wave visits on C3), so the text is re-read 16 code units at a time on such a row
-  // and no register outlives it -- the histogram loop is what runs, and it runs at the occupancy its OWN registers allow
-  // (round 4: the 32 address registers of the rare LCS path had put the whole kernel at 88 VGPRs = 5 waves per SIMD, with
-  // 65 % of the wave-cycles spent waiting for the scalar loads of the histogram loop; <= 64 VGPRs = 8 waves).
+  // PRUNE = false (every row runs the LCS): the text is unpacked once into 32 registers, below.  PRUNE = true: pairs that
+  // reach the LCS are rare (1e-5 on C3) and are scored one by one on the scalar unit (raw_lcs_pair): the histogram loop is
+  // what runs, and it runs at the occupancy its OWN registers allow (round 4: the 32 address registers of the rare LCS
+  // path had put the whole kernel at 88 VGPRs = 5 waves per SIMD, with 65 % of the wave-cycles spent waiting for the scalar
+  // loads of the histogram loop).
   uint32_t taddr[PRUNE ? 1 : 32];
   auto build_taddr = [&](bool narrow) {
     if constexpr (!PRUNE) {
@@ -213,7 +205,6 @@ __global__ __launch_bounds__(kBlock) NSM_C3_OCC void indel_raw_kernel(
   const int i1 = min(p.n_left, i0 + p.rows_per_chunk);
 
   auto build_masks = [&](int i, int la, bool wide) { raw_build_masks(pm, p.pm_stride, lcodes, i, la, wide, lane); };
-  auto lcs_lean = [&](int t, bool wide) -> int { return raw_lcs_lean(rcodes, jc[t], pm_base, wide, npairs); };
 
   // ---- exhaustive kernel: LCS of pattern row i (length la, match masks built here) against the lane's text
   auto lcs_row = [&](int i, int la, bool wide) -> int {
@@ -287,15 +278,18 @@ __global__ __launch_bounds__(kBlock) NSM_C3_OCC void indel_raw_kernel(
       // exact histogram filter, per row: LCS <= sum_c min(hA[c], hB[c]) = (la + lb - L1) / 2 over 32
       // symbol buckets, i.e. the row can only hit if L1 <= la + lb - 2 * lcsmin
       // `who`: bit t set = this lane's string of tile t passed the histogram filter for row i
+      // (the pairs that pass are rare: each is scored on its own on the scalar unit, raw_lcs_pair -- no mask table, and no
+      // register of the LCS outlives it)
       auto score_row = [&](int i, uint32_t who) {
-        build_masks(i, la, wide);
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-          if (!__any((who >> t) & 1u)) continue;
-          const int lcs = lcs_lean(t, wide);
-          const bool hit = lcs >= need[t];
-          if (__any(hit)) {
-            if (hit) emit_hit(hits, p.cap, count, indel_score(la, lbj[t], lcs), lorig[i], rorig[jc[t]]);
+          for (unsigned long long todo = __ballot((who >> t) & 1u); todo; todo &= todo - 1ull) {
+            const int leader = __builtin_ctzll(todo);
+            const int j_s = __builtin_amdgcn_readlane(jc[t], leader);
+            const int lb_s = __builtin_amdgcn_readlane(lbj[t], leader);
+            const int need_s = __builtin_amdgcn_readlane(need[t], leader);
+            const int lcs = raw_lcs_pair(lcodes, i, la, rcodes, j_s, lb_s, lane);
+            if (lcs >= need_s && lane == 0) emit_hit(hits, p.cap, count, indel_score(la, lb_s, lcs), lorig[i], rorig[j_s]);
           }
         }
       };

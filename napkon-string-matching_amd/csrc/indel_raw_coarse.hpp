@@ -19,7 +19,8 @@
 // Every test that drops a pair is an upper bound of the LCS: the hits are the one-stage kernel's, the exhaustive kernel's and
 // the oracle's.  Where the time goes on configs[2] (200k x 200k, threshold 0.8, same box, variant builds NSM_C3C_X_*):
 // scan 3.11 ms (VALU-bound: 64 v_sad_u8 + 16 v_alignbit + one push per batch), pop / re-push 0.11, the 32-bucket test of
-// 4e8 pairs 0.39, 4.1e5 LCS 0.16 -- 3.76 ms against the one-stage kernel's 5.48 (two tiles per wave) and 6.54 (one).
+// 4e8 pairs 0.39, 4.1e5 LCS 0.16 -- 3.76 ms against the one-stage kernel's 5.11 (two tiles per wave; 6.54 with one tile and
+// the wave-wide LCS).
 #pragma once
 
 namespace nsm {
@@ -38,36 +39,6 @@ constexpr int kC3cStack = 192;  // entries per wave; drained when fewer than 64 
 //              | lcsmin bytes
 static inline size_t c3c_lds_bytes(int tiles) {
   return static_cast<size_t>(kWavesPerBlock) * (kC3cStack * 8 + static_cast<size_t>(tiles) * (8 * kWave * 4 + kWave)) + 136;
-}
-
-// LCS of ONE pair (left row `row` of `la`, right row `j` of `lb` code units; all wave-uniform) on the SCALAR unit: lane k
-// holds code unit k of both strings (two 64-byte loads), v_readlane hands the right string's units to the scalar unit one
-// by one, and per unit c the match mask is a ballot -- M = lanes whose left unit equals c -- so the recurrence
-// V' = (V + (V & M)) | (V & ~M) runs on one 64-bit scalar: a v_readlane, a v_cmp and five SALU ops per code unit, no mask
-// table, no LDS, 50 VGPRs for the whole kernel.  (The wave-wide form scores 64 texts against one pattern; with one surviving
-// pair per pattern -- 4.1e5 of them per configs[2] grid -- 63 of its 64 lanes computed nothing: 0.9 of 4.2 ms, and its 32
-// address registers set the kernel's occupancy.)
-__device__ __forceinline__ int raw_lcs_pair(const uint8_t* __restrict__ lcodes, int row, int la, const uint8_t* __restrict__ rcodes,
-                                            int j, int lb, int lane) {
-  // lanes past the pattern hold a value no code unit equals, so the right string's padding (code = alphabet, like the left
-  // string's own) matches nothing and whole words can be processed without a per-unit length test
-  const uint32_t code = lcodes[static_cast<size_t>(row) * 64 + lane];
-  const uint32_t pat = lane < la ? code : 0x100u;
-  const uint32_t text = rcodes[static_cast<size_t>(j) * 64 + lane];
-  unsigned long long v = ~0ull;
-#pragma unroll
-  for (int w = 0; w < 16; ++w) {
-    if (4 * w < lb) {  // (wave-uniform; no `break`: the loop must unroll)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const uint32_t c = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(text), 4 * w + b));
-        const unsigned long long m = __ballot(pat == c);
-        const unsigned long long u = v & m;
-        v = (v + u) | (v & ~m);
-      }
-    }
-  }
-  return __popcll(~v);
 }
 
 #ifndef NSM_C3C_OCC
