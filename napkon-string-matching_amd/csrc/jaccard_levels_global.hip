@@ -232,6 +232,7 @@ int launch_levels_global(const nsm_set_table* l, const nsm_set_table* r, double 
   p.n_left = l->n; p.n_right = r->n; p.vocab = r->vocab; p.partitioned = l->seg != nullptr ? 1 : 0;
   p.lev_stride_l = l->max_levels; p.lev_stride_r = r->max_levels; p.cat_mode = category_mode;
   p.threshold = threshold; p.cap = capacity;
+  if (int rc = check_post_format(r, "nsm_jaccard_levels_grid")) return rc;
   p.row_bits = r->post_row_bits;
   constexpr int kRows = kWave / W;
   p.n_batches = (l->n + kRows - 1) / kRows;

@@ -248,6 +248,7 @@ int launch_raw_global(const nsm_set_table* l, const nsm_set_table* r, double thr
                       unsigned long long* hit_count, hipStream_t stream, bool probe_only, double* estimate) {
   JacGlobalParams<W> p;
   p.n_left = l->n; p.n_right = r->n; p.vocab = r->vocab; p.cap = capacity;
+  if (int rc = check_post_format(r, "nsm_jaccard_raw_grid")) return rc;
   p.row_bits = r->post_row_bits;
   fill_kmin<W>(p.kmin, threshold);
   for (int s = 0; s < 2 * W + 4; ++s)

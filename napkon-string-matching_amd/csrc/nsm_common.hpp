@@ -15,6 +15,20 @@ constexpr uint8_t kNever = 255;      // "no count can reach the threshold"
 void set_error(const char* fmt, ...);
 int hip_status(hipError_t err, const char* what);
 
+// The posting-entry format a table declares (nsm_hip.h: post_format / post_row_bits) must be one the kernels can decode for
+// this many rows of this width: a struct filled for an older ABI, or by hand, would otherwise send them out of bounds.
+inline int check_post_format(const nsm_set_table* t, const char* who) {
+  int width_log = 0;
+  while ((1 << width_log) < t->width) ++width_log;
+  const int f = t->post_format, b = t->post_row_bits;
+  const bool ok = f >= 0 && f <= 2 && (f == 0 ? b == 0 : (b > 0 && b + 2 * width_log <= 32 && static_cast<long long>(t->n) <= (1ll << b)));
+  if (!ok) {
+    set_error("%s: post_format %d with post_row_bits %d does not describe a table of %d rows of width %d", who, f, b, t->n, t->width);
+    return NSM_E_BADARG;
+  }
+  return 0;
+}
+
 // Append one hit.  The counter keeps counting past `cap` so the host can size a retry.
 __device__ __forceinline__ void emit_hit(nsm_hit* __restrict__ hits, unsigned long long cap,
                                          unsigned long long* __restrict__ count, double score, int i,

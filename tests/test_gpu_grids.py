@@ -139,6 +139,16 @@ def test_jaccard_raw_global_index(dev, width, kmax, vocab, n_left, n_right):
             _same_hits(grid.jaccard_raw_grid(lt, rt, thr, index="tile", capacity=1 << 12), want)   # per-tile LDS index
             _same_hits(grid.jaccard_raw_grid(lt, plain, thr, index=True, capacity=1 << 12), want)  # no global index to force
     assert len(want) > 0  # (threshold 1.0: the identical planted rows)
+    # a table that declares a posting format the kernels cannot decode for its rows is refused, not read
+    from napkon_string_matching_amd import _lib
+    for fmt, bits in ((7, rt.post_row_bits), (2, 0), (0, 24), (1, 3)):
+        keep = (rt.post_format, rt.post_row_bits)
+        rt.post_format, rt.post_row_bits = fmt, bits
+        try:
+            with pytest.raises(_lib.NsmLibraryError, match="post_format"):
+                grid.jaccard_raw_grid(lt, rt, 0.5, index=True)
+        finally:
+            rt.post_format, rt.post_row_bits = keep
     # thresholds <= 0: every pair hits, an index cannot help and is not used
     want0 = native.jaccard_raw(native.csr_from_padded(left[:40]), native.csr_from_padded(right[:50]), 0.0, cap=1 << 20)
     lt0 = tables.SetTable.from_padded(left[:40], "left", dev, width=width)
